@@ -1,0 +1,176 @@
+"""ctypes wrapper around oracle/librm_oracle.so (the CPU restatement, rm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  PARITY UNPINNED, see rm_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librm_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile rm_oracle.c with gcc (Makefile in this directory)."""
+    src = os.path.join(_HERE, "rm_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "librm_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.ro_hypot3.restype = C.c_double
+        L.ro_hypot3.argtypes = [C.c_double] * 3
+        L.ro_u8clamp.restype = C.c_uint8
+        L.ro_u8clamp.argtypes = [C.c_double]
+        L.ro_set_length_mode.argtypes = [C.c_int]
+        L.ro_scene_from_preset.restype = C.c_void_p
+        L.ro_scene_from_preset.argtypes = [C.c_int, C.c_char_p]
+        L.ro_scene_from_spheres.restype = C.c_void_p
+        L.ro_scene_from_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        L.ro_scene_free.argtypes = [C.c_void_p]
+        L.ro_scene_set_angles.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ro_scene_distance.restype = C.c_double
+        L.ro_scene_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_run_raymarcher.restype = C.c_int
+        L.ro_run_raymarcher.argtypes = [C.c_void_p, C.c_char_p] + [C.c_void_p] * 4 + \
+            [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.ro_shade.argtypes = [C.c_char_p] + [C.c_void_p] * 5 + [C.c_int, C.c_int]
+        L.ro_diagnostics.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ro_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_scene_root_bounds.restype = C.c_int
+        L.ro_scene_root_bounds.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_scene_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_scene_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleScene:
+    """Mirrors `new Scene(accel); scene.loadPreset(i); scene.camera.setAngles(p, y)`
+    (reference src/workers/raymarchWorker.ts:37-39)."""
+
+    def __init__(self, preset=None, accel="None", spheres=None):
+        L = lib()
+        self.accel = accel
+        if spheres is not None:
+            s = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 4)
+            xyz = np.ascontiguousarray(s[:, :3])
+            rad = np.ascontiguousarray(s[:, 3])
+            self._h = L.ro_scene_from_spheres(_p(xyz), _p(rad), len(s), accel.encode())
+        else:
+            self._h = L.ro_scene_from_preset(int(preset), accel.encode())
+        if not self._h:
+            raise ValueError("preset %r needs non-sphere primitives (out of scope)" % (preset,))
+
+    def close(self):
+        if self._h:
+            lib().ro_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_angles(self, pitch, yaw):
+        lib().ro_scene_set_angles(self._h, float(pitch), float(yaw))
+
+    def camera(self):
+        rot = np.zeros(9, np.float32)
+        org = np.zeros(3, np.float32)
+        lib().ro_scene_camera(self._h, _p(rot), _p(org))
+        return rot, org
+
+    def stats(self):
+        out = np.zeros(8, np.int32)
+        lib().ro_scene_stats(self._h, _p(out))
+        keys = ["bvh_nodes", "bvh_leaves", "bvh_depth", "oct_nodes", "oct_leaves", "oct_empty",
+                "oct_maxleafprims", "n"]
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def root_bounds(self):
+        out = np.zeros(6, np.float32)
+        ok = lib().ro_scene_root_bounds(self._h, _p(out))
+        return out if ok else None
+
+    def spheres(self):
+        n = self.stats()["n"]
+        c = np.zeros((n, 3), np.float32)
+        r = np.zeros(n, np.float64)
+        lib().ro_scene_spheres(self._h, _p(c), _p(r))
+        return c, r
+
+    def distance(self, p):
+        pos = np.asarray(p, np.float32)
+        cnt = C.c_uint32(0)
+        d = lib().ro_scene_distance(self._h, _p(pos), C.byref(cnt))
+        return d, cnt.value
+
+    def render(self, width, height, y_start=0, y_end=None, algorithm="sphere-tracer", time=0.0):
+        """runRaymarcher (reference src/cpu_algorithms/raymarcher.ts:46-109): tile-local buffers."""
+        if y_end is None:
+            y_end = height
+        rows = max(0, y_end - y_start)
+        depth = np.zeros(width * rows, np.uint8)
+        normal = np.zeros(width * rows * 3, np.uint8)
+        sdf = np.zeros(width * rows, np.uint16)
+        iters = np.zeros(width * rows, np.uint16)
+        rc = lib().ro_run_raymarcher(self._h, algorithm.encode(), _p(depth), _p(normal), _p(sdf),
+                                     _p(iters), width, height, float(time), y_start, y_end)
+        if rc != 0:
+            raise NotImplementedError("oracle covers the sphere tracer only (algorithm=%r)" % algorithm)
+        return depth, normal, sdf, iters
+
+
+def shade(model, depth, normal, sdf, iters, width, height):
+    """ShadingModel.shade (reference src/util/shading_models/*.ts)."""
+    out = np.zeros(width * height * 4, np.uint8)
+    lib().ro_shade(model.encode(), _p(out), _p(depth), _p(normal), _p(sdf), _p(iters), width, height)
+    return out
+
+
+def diagnostics(sdf, iters):
+    """main.ts:528-548 -> dict(total_sdf, max_sdf, min_sdf, total_iters)."""
+    out = np.zeros(4, np.float64)
+    lib().ro_diagnostics(_p(sdf), _p(iters), sdf.size, _p(out))
+    return {"total_sdf": int(out[0]), "max_sdf": int(out[1]), "min_sdf": int(out[2]),
+            "total_iters": int(out[3])}
+
+
+def synthetic_spheres(n=10000, seed=0x5EED5EED):
+    """splitmix64, centres uniform in [-1.5,1.5]^3 then fround, radii uniform
+    in [0.01,0.04] kept as doubles.  Returns float64 [n,4] (x,y,z,r)."""
+    mask = (1 << 64) - 1
+    state = seed & mask
+
+    def nxt():
+        nonlocal state
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z = z ^ (z >> 31)
+        return (z >> 11) * (1.0 / 9007199254740992.0)
+
+    out = np.zeros((n, 4), np.float64)
+    for i in range(n):
+        for k in range(3):
+            out[i, k] = np.float32(-1.5 + 3.0 * nxt())
+        out[i, 3] = 0.01 + 0.03 * nxt()
+    return out

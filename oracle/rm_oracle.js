@@ -1,0 +1,503 @@
+'use strict';
+/*
+ * rm_oracle.js -- second, independently written restatement of the reference's per-pixel
+ * sphere-tracing path, for a real JS engine (node).
+ *
+ * TEST INFRASTRUCTURE ONLY.  It exists so that the C oracle (rm_oracle.c) can be
+ * cross-checked, byte for byte, against the same algorithm evaluated with genuine JS
+ * number semantics (Math.hypot, Math.min/max, Float32Array / Uint8ClampedArray /
+ * Uint16Array stores, Array.prototype.sort stability), and to produce the fixtures under
+ * tests/golden/ (tests/golden/make_golden.py drives it).  It never runs on the GPU box and
+ * nothing in the product imports it.  PARITY UNPINNED (see rm_oracle.c header): the
+ * gl-matrix helpers below restate the published 3.x formulas, gl-matrix itself is absent.
+ *
+ * Written in a different shape from the C file on purpose (flat node tables, iterative
+ * point queries) so that agreement between the two means something.
+ *
+ * usage: node rm_oracle.js render <config.json> <outdir>
+ *        node rm_oracle.js hypot  <in.f64 triples> <out.f64>
+ *        node rm_oracle.js camera <in.f64 pitch,yaw pairs> <out.f32 x12>
+ */
+const fs = require('fs');
+const path = require('path');
+const crypto = require('crypto');
+
+const fr = Math.fround; // == one Float32Array element store
+
+// ---------------------------------------------------------------- gl-matrix subset
+function m4identity() { const m = new Float32Array(16); m[0] = m[5] = m[10] = m[15] = 1; return m; }
+
+function m4fromRTS(q, v, s) { // mat4.fromRotationTranslationScale
+  const o = new Float32Array(16);
+  const x = q[0], y = q[1], z = q[2], w = q[3];
+  const x2 = x + x, y2 = y + y, z2 = z + z;
+  const xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2;
+  const wx = w * x2, wy = w * y2, wz = w * z2;
+  o[0] = (1 - (yy + zz)) * s[0]; o[1] = (xy + wz) * s[0]; o[2] = (xz - wy) * s[0]; o[3] = 0;
+  o[4] = (xy - wz) * s[1]; o[5] = (1 - (xx + zz)) * s[1]; o[6] = (yz + wx) * s[1]; o[7] = 0;
+  o[8] = (xz + wy) * s[2]; o[9] = (yz - wx) * s[2]; o[10] = (1 - (xx + yy)) * s[2]; o[11] = 0;
+  o[12] = v[0]; o[13] = v[1]; o[14] = v[2]; o[15] = 1;
+  return o;
+}
+
+function m4invert(out, a) { // mat4.invert, cofactor form; null when det is falsy
+  const a00 = a[0], a01 = a[1], a02 = a[2], a03 = a[3], a10 = a[4], a11 = a[5], a12 = a[6], a13 = a[7];
+  const a20 = a[8], a21 = a[9], a22 = a[10], a23 = a[11], a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+  const b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10, b02 = a00 * a13 - a03 * a10;
+  const b03 = a01 * a12 - a02 * a11, b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
+  const b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30, b08 = a20 * a33 - a23 * a30;
+  const b09 = a21 * a32 - a22 * a31, b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
+  let det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+  if (!det) return null;
+  det = 1.0 / det;
+  out[0] = (a11 * b11 - a12 * b10 + a13 * b09) * det;
+  out[1] = (a02 * b10 - a01 * b11 - a03 * b09) * det;
+  out[2] = (a31 * b05 - a32 * b04 + a33 * b03) * det;
+  out[3] = (a22 * b04 - a21 * b05 - a23 * b03) * det;
+  out[4] = (a12 * b08 - a10 * b11 - a13 * b07) * det;
+  out[5] = (a00 * b11 - a02 * b08 + a03 * b07) * det;
+  out[6] = (a32 * b02 - a30 * b05 - a33 * b01) * det;
+  out[7] = (a20 * b05 - a22 * b02 + a23 * b01) * det;
+  out[8] = (a10 * b10 - a11 * b08 + a13 * b06) * det;
+  out[9] = (a01 * b08 - a00 * b10 - a03 * b06) * det;
+  out[10] = (a30 * b04 - a31 * b02 + a33 * b00) * det;
+  out[11] = (a21 * b02 - a20 * b04 - a23 * b00) * det;
+  out[12] = (a11 * b07 - a10 * b09 - a12 * b06) * det;
+  out[13] = (a00 * b09 - a01 * b07 + a02 * b06) * det;
+  out[14] = (a31 * b01 - a30 * b03 - a32 * b00) * det;
+  out[15] = (a20 * b03 - a21 * b01 + a22 * b00) * det;
+  return out;
+}
+
+function m4rotY(a, rad) { // mat4.rotateY into a fresh matrix
+  const o = new Float32Array(a), s = Math.sin(rad), c = Math.cos(rad);
+  for (let k = 0; k < 4; k++) { o[k] = a[k] * c - a[8 + k] * s; o[8 + k] = a[k] * s + a[8 + k] * c; }
+  return o;
+}
+function m4rotX(a, rad) { // mat4.rotateX into a fresh matrix
+  const o = new Float32Array(a), s = Math.sin(rad), c = Math.cos(rad);
+  for (let k = 0; k < 4; k++) { o[4 + k] = a[4 + k] * c + a[8 + k] * s; o[8 + k] = a[8 + k] * c - a[4 + k] * s; }
+  return o;
+}
+function m4translate(a, v) { // mat4.translate into a fresh matrix
+  const o = new Float32Array(a), x = v[0], y = v[1], z = v[2];
+  for (let k = 0; k < 4; k++) o[12 + k] = a[k] * x + a[4 + k] * y + a[8 + k] * z + a[12 + k];
+  return o;
+}
+
+// ---------------------------------------------------------------- camera (camera.ts)
+function cameraMatrix(pitch, yaw) {
+  const p = Math.min(Math.max(pitch, -Math.PI / 2), Math.PI / 2);
+  const orbit = m4rotX(m4rotY(m4identity(), yaw), p);
+  return m4translate(orbit, new Float32Array([0, 0, Math.abs(3)]));
+}
+
+// ---------------------------------------------------------------- scene tables
+// prims: {T: Float32Array(16) world->local, r: double, c: Float32Array(3) world position,
+//         lo/hi: Float32Array(3) padded AABB}
+function makeSphere(x, y, z, r) {
+  const model = m4fromRTS([0, 0, 0, 1], [x, y, z], [1, 1, 1]);
+  const T = m4identity(); m4invert(T, model);
+  const back = m4identity(); const ok = m4invert(back, T);
+  const c = new Float32Array([back[12], back[13], back[14]]);
+  const m = ok ? back : T;
+  const sc = Math.max(Math.hypot(m[0], m[1], m[2]), Math.hypot(m[4], m[5], m[6]), Math.hypot(m[8], m[9], m[10]));
+  const pad = r * sc * 1.5;
+  const lo = new Float32Array([c[0] - pad, c[1] - pad, c[2] - pad]);
+  const hi = new Float32Array([c[0] + pad, c[1] + pad, c[2] + pad]);
+  return { T, r, c, lo, hi };
+}
+
+function presetSpheres(index) {
+  const i = Math.max(0, Math.min(index, 18));
+  const out = [];
+  if (i === 0) out.push([0, 0, 0, 1.5]);
+  else if (i === 1) out.push([0.8, -0.3, 0.2, 0.4], [-0.5, 0.9, -0.1, 0.5], [0.2, 0.1, 0.8, 0.3], [-0.9, -0.4, -0.6, 0.6],
+    [0.4, -0.8, 0.5, 0.35], [-0.2, 0.6, -0.9, 0.4], [0.7, 0.3, -0.4, 0.25]);
+  else if (i === 2) { for (let y = -1; y <= 1; y++) for (let x = -1; x <= 1; x++) out.push([x, y, 0, 0.3]); }
+  else if (i === 3) {
+    const g = 5, sp = 0.6, off = (g - 1) * sp / 2;
+    for (let x = 0; x < g; x++) for (let y = 0; y < g; y++) for (let z = 0; z < g; z++) out.push([x * sp - off, y * sp - off, z * sp - off, 0.15]);
+  } else if (i === 4) out.push([0, 0, 0, 0.5], [1.2, 0, 0, 0.3], [-1.2, 0, 0, 0.3], [0, 1.2, 0, 0.3], [0, -1.2, 0, 0.3], [0, 0, 1.2, 0.3], [0, 0, -1.2, 0.3]);
+  else throw new Error('preset ' + i + ' needs non-sphere primitives (out of scope)');
+  return out;
+}
+
+function unionBox(prims, ids) { // computeBounds: fold of merge, f32 at every step
+  if (ids.length === 0) return { lo: new Float32Array(3), hi: new Float32Array(3) };
+  const lo = new Float32Array(prims[ids[0]].lo), hi = new Float32Array(prims[ids[0]].hi);
+  for (let k = 1; k < ids.length; k++) for (let a = 0; a < 3; a++) {
+    lo[a] = Math.min(lo[a], prims[ids[k]].lo[a]); hi[a] = Math.max(hi[a], prims[ids[k]].hi[a]);
+  }
+  return { lo, hi };
+}
+
+// BVH as parallel arrays; node = index.  bvh.ts:29-92
+function buildBVH(prims) {
+  const B = { lo: [], hi: [], L: [], R: [], P: [], leaves: 0, depth: 0 };
+  function rec(ids, box, depth) {
+    const me = B.lo.length;
+    B.lo.push(box.lo); B.hi.push(box.hi); B.L.push(-1); B.R.push(-1); B.P.push(null);
+    if (depth > B.depth) B.depth = depth;
+    if (depth >= 20 || ids.length <= 2) { B.P[me] = ids; B.leaves++; return me; }
+    const ext = new Float32Array(3);
+    for (let a = 0; a < 3; a++) ext[a] = box.hi[a] - box.lo[a];
+    let axis = 0; if (ext[1] > ext[0]) axis = 1; if (ext[2] > ext[axis]) axis = 2;
+    const order = ids.slice().sort((p, q) => prims[p].c[axis] - prims[q].c[axis]);
+    const mid = Math.floor(order.length / 2);
+    const lh = order.slice(0, mid), rh = order.slice(mid);
+    if (lh.length === 0 || rh.length === 0) { B.P[me] = ids; B.leaves++; return me; }
+    B.L[me] = rec(lh, unionBox(prims, lh), depth + 1);
+    B.R[me] = rec(rh, unionBox(prims, rh), depth + 1);
+    return me;
+  }
+  const all = prims.map((_, i) => i);
+  rec(all, unionBox(prims, all), 0);
+  return B;
+}
+
+function inBox(lo, hi, p) {
+  return p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2];
+}
+
+function slab(lo, hi, o, d) { // boundingBox.ts:69-105
+  let tn = -Infinity, tf = Infinity;
+  for (let a = 0; a < 3; a++) {
+    if (Math.abs(d[a]) < 1e-10) { if (o[a] < lo[a] || o[a] > hi[a]) return null; }
+    else {
+      const inv = 1.0 / d[a];
+      let t0 = (lo[a] - o[a]) * inv, t1 = (hi[a] - o[a]) * inv;
+      if (t0 > t1) { const t = t0; t0 = t1; t1 = t; }
+      tn = Math.max(tn, t0); tf = Math.min(tf, t1);
+      if (tn > tf) return null;
+    }
+  }
+  return [tn, tf];
+}
+
+function bvhIntervals(B, o, d, tLo, tHi) { // bvh.ts:126-178
+  const found = [], todo = [0];
+  while (todo.length) {
+    const n = todo.pop();
+    const h = slab(B.lo[n], B.hi[n], o, d);
+    if (!h) continue;
+    if (h[1] < tLo || h[0] > tHi) continue;
+    if (B.L[n] >= 0 || B.R[n] >= 0) { if (B.L[n] >= 0) todo.push(B.L[n]); if (B.R[n] >= 0) todo.push(B.R[n]); }
+    else if (B.P[n] && B.P[n].length > 0) found.push({ a: Math.max(h[0], tLo), b: Math.min(h[1], tHi) });
+  }
+  found.sort((u, v) => u.a - v.a);
+  return found;
+}
+
+function bvhPointPrims(B, p) { // bvh.ts:95-121 (left before right, Set semantics)
+  const seen = new Set(), todo = [0];
+  while (todo.length) {
+    const n = todo.pop();
+    if (!inBox(B.lo[n], B.hi[n], p)) continue;
+    if (B.L[n] < 0 && B.R[n] < 0) { for (const id of B.P[n]) seen.add(id); continue; }
+    if (B.R[n] >= 0) todo.push(B.R[n]);
+    if (B.L[n] >= 0) todo.push(B.L[n]);
+  }
+  return Array.from(seen);
+}
+
+// Octree as parallel arrays.  octree.ts:36-191
+function boxGap(alo, ahi, blo, bhi) { // boundingBox.ts:33-47
+  const g = [0, 0, 0];
+  for (let a = 0; a < 3; a++) {
+    if (ahi[a] < blo[a]) g[a] = blo[a] - ahi[a]; else if (bhi[a] < alo[a]) g[a] = alo[a] - bhi[a];
+  }
+  return Math.hypot(g[0], g[1], g[2]);
+}
+function buildOctree(prims) {
+  const O = { lo: [], hi: [], kids: [], P: [], level: [], empty: [], minD: [] };
+  function add(lo, hi, level) {
+    O.lo.push(lo); O.hi.push(hi); O.kids.push(null); O.P.push([]); O.level.push(level); O.empty.push(true); O.minD.push(0);
+    return O.lo.length - 1;
+  }
+  function rec(ids, lo, hi, depth) {
+    const me = add(lo, hi, depth);
+    if (depth >= 6 || ids.length <= 4) { O.P[me] = ids; return me; }
+    const c = new Float32Array([(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2]);
+    const cl = [], ch = [];
+    for (let k = 0; k < 8; k++) {
+      const bx = k & 1, by = (k >> 1) & 1, bz = (k >> 2) & 1;
+      cl.push(new Float32Array([bx ? c[0] : lo[0], by ? c[1] : lo[1], bz ? c[2] : lo[2]]));
+      ch.push(new Float32Array([bx ? hi[0] : c[0], by ? hi[1] : c[1], bz ? hi[2] : c[2]]));
+    }
+    const share = [[], [], [], [], [], [], [], []];
+    for (const id of ids) for (let k = 0; k < 8; k++) {
+      const q = prims[id];
+      if (cl[k][0] <= q.hi[0] && ch[k][0] >= q.lo[0] && cl[k][1] <= q.hi[1] && ch[k][1] >= q.lo[1] && cl[k][2] <= q.hi[2] && ch[k][2] >= q.lo[2]) share[k].push(id);
+    }
+    const kids = [];
+    for (let k = 0; k < 8; k++) kids.push(share[k].length > 0 ? rec(share[k], cl[k], ch[k], depth + 1) : add(cl[k], ch[k], depth + 1));
+    O.kids[me] = kids;
+    return me;
+  }
+  rec(prims.map((_, i) => i), new Float32Array([-10, -10, -10]), new Float32Array([10, 10, 10]), 0);
+  function nearest(n) {
+    let best = Infinity;
+    for (const q of prims) { const g = boxGap(O.lo[n], O.hi[n], q.lo, q.hi); if (g < best) best = g; }
+    return best !== Infinity ? Math.max(0, best) : 0;
+  }
+  function mark(n) {
+    if (!O.kids[n]) { const has = O.P[n].length > 0; O.empty[n] = !has; O.minD[n] = has ? 0 : nearest(n); return has; }
+    let any = false;
+    for (const k of O.kids[n]) if (mark(k)) any = true;
+    O.empty[n] = !any; O.minD[n] = any ? 0 : nearest(n);
+    return any;
+  }
+  mark(0);
+  return O;
+}
+function octFind(O, p) { // octree.ts:223-248
+  function rec(n) {
+    if (!inBox(O.lo[n], O.hi[n], p)) return -1;
+    if (!O.kids[n] || O.level[n] === 6) return n;
+    for (const k of O.kids[n]) { const f = rec(k); if (f >= 0) return f; }
+    return n;
+  }
+  return rec(0);
+}
+const _tA = new Float32Array(3), _tB = new Float32Array(3);
+function octSkip(O, o, d, t) { // octree.ts:252-278 + 195-220
+  const p = new Float32Array([o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t]);
+  const n = octFind(O, p);
+  if (n < 0) return 0;
+  if (O.empty[n]) {
+    for (let a = 0; a < 3; a++) {
+      const inv = 1.0 / d[a];
+      let t0 = (O.lo[n][a] - o[a]) * inv, t1 = (O.hi[n][a] - o[a]) * inv;
+      if (inv < 0.0) { const s = t0; t0 = t1; t1 = s; }
+      _tA[a] = t0; _tB[a] = t1;
+    }
+    const tIn = Math.max(_tA[0], _tA[1], _tA[2]), tOut = Math.min(_tB[0], _tB[1], _tB[2]);
+    if (!(tIn > tOut || tOut < 0)) {
+      const toExit = Math.max(0, tOut - t);
+      const step = Math.max(0, Math.min(toExit, O.minD[n] * 0.99));
+      return step > 0 ? step + 0.001 : 0;
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- scene distance
+function sphereSdf(q, p, useSqrt) { // primitive.ts:33-39, sphere.ts:12-14
+  const m = q.T, x = p[0], y = p[1], z = p[2];
+  let w = m[3] * x + m[7] * y + m[11] * z + m[15]; w = w || 1.0;
+  const lx = fr((m[0] * x + m[4] * y + m[8] * z + m[12]) / w);
+  const ly = fr((m[1] * x + m[5] * y + m[9] * z + m[13]) / w);
+  const lz = fr((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
+  const len = useSqrt ? Math.sqrt(lx * lx + ly * ly + lz * lz) : Math.hypot(lx, ly, lz);
+  return len - q.r;
+}
+
+function makeScene(spheres, accel, useSqrt) {
+  const prims = spheres.map(s => makeSphere(s[0], s[1], s[2], s[3]));
+  const S = { prims, accel, bvh: null, oct: null, useSqrt: !!useSqrt };
+  if (accel === 'BVH') S.bvh = buildBVH(prims);
+  else if (accel === 'Octree') S.oct = buildOctree(prims);
+  else S.accel = 'None';
+  return S;
+}
+
+function sceneDistance(S, p, tally) { // scene.ts:144-190; tally[0] += evaluations
+  let best = 10;
+  const prims = S.prims;
+  if (S.accel === 'Octree') {
+    const n = octFind(S.oct, p);
+    if (n >= 0) {
+      const ids = S.oct.P[n];
+      if (ids.length > 0) { for (const id of ids) { tally[0]++; best = Math.min(sphereSdf(prims[id], p, S.useSqrt), best); } }
+      else if (S.oct.empty[n]) best = Math.min(best, S.oct.minD[n] * 0.99);
+      return best;
+    }
+  } else if (S.accel === 'BVH') {
+    let ids = bvhPointPrims(S.bvh, p);
+    if (ids.length === 0) ids = prims.map((_, i) => i);
+    for (const id of ids) { tally[0]++; best = Math.min(sphereSdf(prims[id], p, S.useSqrt), best); }
+    return best;
+  }
+  for (let id = 0; id < prims.length; id++) { tally[0]++; best = Math.min(sphereSdf(prims[id], p, S.useSqrt), best); }
+  return best;
+}
+
+// ---------------------------------------------------------------- tile render
+function renderTile(S, cam, W, H, y0, y1) {
+  const rows = Math.max(0, y1 - y0);
+  const depth = new Uint8ClampedArray(W * rows), normal = new Uint8ClampedArray(W * rows * 3);
+  const sdf = new Uint16Array(W * rows), iters = new Uint16Array(W * rows);
+  const R = [cam[0], cam[1], cam[2], cam[4], cam[5], cam[6], cam[8], cam[9], cam[10]]; // mat3.fromMat4
+  const o = new Float32Array([cam[12], cam[13], cam[14]]);
+  const d = new Float32Array(3), p = new Float32Array(3), q = new Float32Array(3), nrm = new Float32Array(3);
+  const tally = [0];
+  function dist(at, px) { tally[0] = 0; const v = sceneDistance(S, at, tally); sdf[px] += tally[0]; return v; }
+
+  function march(px) { // sphereTracer.ts:15-83
+    let t = 0, list = null, cur = 0;
+    if (S.accel === 'BVH') { list = bvhIntervals(S.bvh, o, d, 0, 10); if (list.length === 0) return 10; }
+    for (let i = 0; i < 100; i++) {
+      p[0] = o[0] + d[0] * t; p[1] = o[1] + d[1] * t; p[2] = o[2] + d[2] * t;
+      if (S.accel !== 'None') {
+        let skip = 0;
+        if (S.accel === 'BVH') {
+          if (cur >= list.length) skip = -1;
+          else if (t < list[cur].a) skip = list[cur].a - t;
+          else if (t > list[cur].b) {
+            cur++;
+            if (cur < list.length) { if (list[cur].a > t) skip = list[cur].a - t; }
+            else skip = -1;
+          }
+        } else skip = octSkip(S.oct, o, d, t);
+        if (skip === -1) return 10;
+        if (skip > 0) { t += skip; if (t > 10) break; continue; }
+      }
+      const dd = dist(p, px);
+      t += dd;
+      iters[px] += 1;
+      if (dd < 0.001) break;
+      if (t > 10) break;
+    }
+    return t;
+  }
+
+  for (let y = y0; y < y1; y++) {
+    const v = (y / H - 0.5) * 2.0;
+    for (let x = 0; x < W; x++) {
+      const px = (y - y0) * W + x;
+      sdf[px] = 0; iters[px] = 0;
+      const u = (x / W - 0.5) * 2.0;
+      d[0] = u; d[1] = v; d[2] = -1;
+      const ax = d[0], ay = d[1], az = d[2];
+      d[0] = ax * R[0] + ay * R[3] + az * R[6];
+      d[1] = ax * R[1] + ay * R[4] + az * R[7];
+      d[2] = ax * R[2] + ay * R[5] + az * R[8];
+      let len = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+      if (len > 0) len = 1 / Math.sqrt(len);
+      d[0] = d[0] * len; d[1] = d[1] * len; d[2] = d[2] * len;
+
+      const t = march(px);
+      q[0] = o[0] + d[0] * t; q[1] = o[1] + d[1] * t; q[2] = o[2] + d[2] * t;
+      nrm[0] = 0; nrm[1] = 0; nrm[2] = 0;
+      if (!(t >= 10)) { // raymarcher.ts:123-135
+        const base = dist(q, px);
+        const s = new Float32Array(3);
+        s[0] = q[0] - 0.01; s[1] = q[1]; s[2] = q[2]; nrm[0] = base - dist(s, px);
+        s[0] = q[0]; s[1] = q[1] - 0.01; s[2] = q[2]; nrm[1] = base - dist(s, px);
+        s[0] = q[0]; s[1] = q[1]; s[2] = q[2] - 0.01; nrm[2] = base - dist(s, px);
+        let l2 = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+        if (l2 > 0) l2 = 1 / Math.sqrt(l2);
+        nrm[0] = nrm[0] * l2; nrm[1] = nrm[1] * l2; nrm[2] = nrm[2] * l2;
+      }
+      normal[3 * px] = (nrm[0] + 1) * 0.5 * 255;
+      normal[3 * px + 1] = (nrm[1] + 1) * 0.5 * 255;
+      normal[3 * px + 2] = (nrm[2] + 1) * 0.5 * 255;
+      depth[px] = t;
+    }
+  }
+  return { depth, normal, sdf, iters };
+}
+
+// ---------------------------------------------------------------- shading
+function shade(model, depth, normal, sdf, iters, W, H) {
+  const out = new Uint8ClampedArray(W * H * 4), n = W * H;
+  if (model === 'sdf-heatmap' || model === 'iteration-heatmap') {
+    const src = model === 'sdf-heatmap' ? sdf : iters;
+    for (let i = 0; i < n; i++) {
+      const k = src[i] * 5 % 256;
+      out[4 * i] = Math.min(2 * k, 255); out[4 * i + 1] = Math.min(-2 * k + 512, 255); out[4 * i + 2] = 0; out[4 * i + 3] = 255;
+    }
+  } else if (model === 'phong') {
+    const L = new Float32Array([1, -1, 1.5]);
+    let ll = L[0] * L[0] + L[1] * L[1] + L[2] * L[2]; ll = 1 / Math.sqrt(ll);
+    L[0] = L[0] * ll; L[1] = L[1] * ll; L[2] = L[2] * ll;
+    const N = new Float32Array(3), Rf = new Float32Array(3);
+    for (let i = 0; i < n; i++) {
+      const dz = depth[i];
+      if (dz >= 255) { out[4 * i] = 10; out[4 * i + 1] = 10; out[4 * i + 2] = 20; out[4 * i + 3] = 255; continue; }
+      N[0] = normal[3 * i] / 127.5 - 1.0; N[1] = normal[3 * i + 1] / 127.5 - 1.0; N[2] = normal[3 * i + 2] / 127.5 - 1.0;
+      let l2 = N[0] * N[0] + N[1] * N[1] + N[2] * N[2]; if (l2 > 0) l2 = 1 / Math.sqrt(l2);
+      N[0] = N[0] * l2; N[1] = N[1] * l2; N[2] = N[2] * l2;
+      const ndl = N[0] * L[0] + N[1] * L[1] + N[2] * L[2];
+      const diffuse = Math.max(ndl, 0);
+      const k2 = 2 * ndl;
+      Rf[0] = N[0] * k2; Rf[1] = N[1] * k2; Rf[2] = N[2] * k2;
+      Rf[0] = Rf[0] - L[0]; Rf[1] = Rf[1] - L[1]; Rf[2] = Rf[2] - L[2];
+      let r2 = Rf[0] * Rf[0] + Rf[1] * Rf[1] + Rf[2] * Rf[2]; if (r2 > 0) r2 = 1 / Math.sqrt(r2);
+      Rf[0] = Rf[0] * r2; Rf[1] = Rf[1] * r2; Rf[2] = Rf[2] * r2;
+      const vdr = 0 * Rf[0] + 0 * Rf[1] + 1 * Rf[2];
+      const spec = 0.5 * Math.pow(Math.max(vdr, 0), 32);
+      const inten = Math.min(0.1 + diffuse + spec, 1);
+      const col = 255 * inten * (1 - dz / 255);
+      out[4 * i] = col; out[4 * i + 1] = col; out[4 * i + 2] = col; out[4 * i + 3] = 255;
+    }
+  } else {
+    for (let i = 0; i < n; i++) { out[4 * i] = normal[3 * i]; out[4 * i + 1] = normal[3 * i + 1]; out[4 * i + 2] = normal[3 * i + 2]; out[4 * i + 3] = 255; }
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------- driver
+function sha(buf) { return crypto.createHash('sha256').update(Buffer.from(buf.buffer, buf.byteOffset, buf.byteLength)).digest('hex'); }
+
+function cmdRender(cfgPath, outDir) {
+  const cfg = JSON.parse(fs.readFileSync(cfgPath, 'utf8'));
+  let spheres;
+  if (cfg.spheres_file) {
+    const raw = fs.readFileSync(cfg.spheres_file);
+    const f = new Float64Array(raw.buffer, raw.byteOffset, raw.byteLength / 8);
+    spheres = [];
+    for (let i = 0; i + 3 < f.length; i += 4) spheres.push([f[i], f[i + 1], f[i + 2], f[i + 3]]);
+  } else spheres = presetSpheres(cfg.preset);
+  const S = makeScene(spheres, cfg.accel, cfg.length_sqrt);
+  const cam = cameraMatrix(cfg.pitch || 0, cfg.yaw || 0);
+  const W = cfg.width, H = cfg.height;
+  const y0 = cfg.yStart === undefined ? 0 : cfg.yStart, y1 = cfg.yEnd === undefined ? H : cfg.yEnd;
+  const t0 = process.hrtime.bigint();
+  const r = renderTile(S, cam, W, H, y0, y1);
+  const t1 = process.hrtime.bigint();
+  const rgba = shade(cfg.shader || 'normal', r.depth, r.normal, r.sdf, r.iters, W, y1 - y0);
+  let sumS = 0, sumI = 0, mx = 0, mn = Number.MAX_SAFE_INTEGER;
+  for (let i = 0; i < r.sdf.length; i++) { const c = r.sdf[i]; sumS += c; sumI += r.iters[i]; if (c > mx) mx = c; if (c < mn) mn = c; }
+  if (outDir) {
+    fs.mkdirSync(outDir, { recursive: true });
+    const w = (name, a) => fs.writeFileSync(path.join(outDir, name), Buffer.from(a.buffer, a.byteOffset, a.byteLength));
+    w('depth.bin', r.depth); w('normal.bin', r.normal); w('sdf.bin', r.sdf); w('iters.bin', r.iters); w('rgba.bin', rgba);
+  }
+  const stats = {
+    width: W, height: H, yStart: y0, yEnd: y1, n_prims: spheres.length,
+    sum_sdf: sumS, max_sdf: mx, min_sdf: mn, sum_iters: sumI, render_ms: Number(t1 - t0) / 1e6,
+    sha256: { depth: sha(r.depth), normal: sha(r.normal), sdf: sha(r.sdf), iters: sha(r.iters), rgba: sha(rgba) },
+    bvh: S.bvh ? { nodes: S.bvh.lo.length, leaves: S.bvh.leaves, depth: S.bvh.depth } : null,
+    octree: S.oct ? { nodes: S.oct.lo.length } : null,
+    engine: 'node ' + process.version + ' v8 ' + process.versions.v8,
+  };
+  process.stdout.write(JSON.stringify(stats) + '\n');
+}
+
+function cmdHypot(inPath, outPath) {
+  const raw = fs.readFileSync(inPath);
+  const f = new Float64Array(raw.buffer, raw.byteOffset, raw.byteLength / 8);
+  const out = new Float64Array(f.length / 3);
+  for (let i = 0; i < out.length; i++) out[i] = Math.hypot(f[3 * i], f[3 * i + 1], f[3 * i + 2]);
+  fs.writeFileSync(outPath, Buffer.from(out.buffer));
+}
+
+function cmdCamera(inPath, outPath) {
+  const raw = fs.readFileSync(inPath);
+  const f = new Float64Array(raw.buffer, raw.byteOffset, raw.byteLength / 8);
+  const out = new Float32Array(f.length / 2 * 12);
+  for (let i = 0; i < f.length / 2; i++) {
+    const c = cameraMatrix(f[2 * i], f[2 * i + 1]);
+    const v = [c[0], c[1], c[2], c[4], c[5], c[6], c[8], c[9], c[10], c[12], c[13], c[14]];
+    for (let k = 0; k < 12; k++) out[12 * i + k] = v[k];
+  }
+  fs.writeFileSync(outPath, Buffer.from(out.buffer));
+}
+
+const [cmd, a1, a2] = process.argv.slice(2);
+if (cmd === 'render') cmdRender(a1, a2);
+else if (cmd === 'hypot') cmdHypot(a1, a2);
+else if (cmd === 'camera') cmdCamera(a1, a2);
+else { process.stderr.write('usage: node rm_oracle.js render|hypot|camera ...\n'); process.exit(2); }

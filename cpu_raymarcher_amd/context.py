@@ -1,0 +1,153 @@
+"""One rm_ctx per GPU (include/rm_raymarch.h "Threading"): owns the device-resident scene."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """void* of a numpy array (host) or a torch tensor (device); None -> NULL."""
+    if x is None:
+        return None
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(C.c_void_p)
+
+
+def _current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Context:
+    """`device` >= 0 binds a GPU; device=None creates a host-only context (scene building
+    and camera only -- every render entry then fails with RM_E_NO_DEVICE: no CPU path)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self.device = -1 if device is None else int(device)
+        rc = N.lib().rm_create(self.device, C.byref(self._h))
+        if rc != N.RM_OK:
+            raise N.RmError(rc, "rm_create(device=%d) failed: no usable HIP device" % self.device)
+
+    def close(self):
+        if self._h:
+            N.lib().rm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- options (never change results) -------------------------------------------
+    def set_option(self, key, value):
+        N.check(self._h, N.lib().rm_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        N.check(self._h, N.lib().rm_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # ---- scene ----------------------------------------------------------------------
+    def scene_from_preset(self, index, accel):
+        N.check(self._h, N.lib().rm_scene_from_preset(self._h, int(index), int(accel)))
+
+    def scene_from_spheres(self, centers, radii, accel):
+        c = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(radii, dtype=np.float64).reshape(-1)
+        if len(c) != len(r):
+            raise ValueError("centers and radii differ in length")
+        N.check(self._h, N.lib().rm_scene_from_spheres(self._h, _ptr(c), _ptr(r), len(r), int(accel)))
+
+    def scene_info(self):
+        info = N.rm_scene_info()
+        N.check(self._h, N.lib().rm_scene_get_info(self._h, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in info._fields_ if k not in ("root_min", "root_max", "reserved")}
+        d["root_min"] = [float(v) for v in info.root_min]
+        d["root_max"] = [float(v) for v in info.root_max]
+        return d
+
+    def scene_distance(self, points):
+        """Scene.getDistance for a batch of points -> (dist float64[n], count uint32[n])."""
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        dist = np.zeros(len(p), np.float64)
+        cnt = np.zeros(len(p), np.uint32)
+        N.check(self._h, N.lib().rm_scene_distance(self._h, _ptr(p), len(p), _ptr(dist), _ptr(cnt)))
+        return dist, cnt
+
+    # ---- render ---------------------------------------------------------------------
+    def render_tile(self, job, depth, normal, sdf, iters, rgba=None, shader=0):
+        """Host numpy buffers -> rm_render_tile (+ rm_shade when rgba is given); torch CUDA
+        tensors -> rm_render_tile_device on torch's current stream (fused shade)."""
+        bufs = [b for b in (depth, normal, sdf, iters, rgba) if b is not None]
+        if bufs and all(_is_torch(b) for b in bufs):
+            for b in bufs:
+                if not b.is_cuda or not b.is_contiguous():
+                    raise ValueError("device buffers must be contiguous CUDA tensors")
+            N.check(self._h, N.lib().rm_render_tile_device(
+                self._h, C.byref(job), int(shader), _ptr(depth), _ptr(normal), _ptr(sdf), _ptr(iters),
+                _ptr(rgba), _current_stream_ptr()))
+            return
+        N.check(self._h, N.lib().rm_render_tile(self._h, C.byref(job), _ptr(depth), _ptr(normal),
+                                                 _ptr(sdf), _ptr(iters)))
+        if rgba is not None:
+            rows = max(0, job.y_end - job.y_start)
+            self.shade(shader, job.width, rows, depth, normal, sdf, iters, rgba)
+
+    def shade(self, shader, width, height, depth, normal, sdf, iters, rgba):
+        if _is_torch(rgba):
+            N.check(self._h, N.lib().rm_shade_device(self._h, int(shader), width, height, _ptr(depth),
+                                                      _ptr(normal), _ptr(sdf), _ptr(iters), _ptr(rgba),
+                                                      _current_stream_ptr()))
+        else:
+            N.check(self._h, N.lib().rm_shade(self._h, int(shader), width, height, _ptr(depth), _ptr(normal),
+                                               _ptr(sdf), _ptr(iters), _ptr(rgba)))
+
+    def reduce_counters(self, sdf, iters):
+        out = N.rm_diagnostics()
+        n = int(sdf.numel()) if _is_torch(sdf) else int(sdf.size)
+        if _is_torch(sdf):
+            N.check(self._h, N.lib().rm_reduce_counters_device(self._h, _ptr(sdf), _ptr(iters), n,
+                                                                C.byref(out), _current_stream_ptr()))
+        else:
+            N.check(self._h, N.lib().rm_reduce_counters(self._h, _ptr(sdf), _ptr(iters), n, C.byref(out)))
+        return {"total_sdf": int(out.total_sdf_calls), "total_iters": int(out.total_iterations),
+                "max_sdf": int(out.max_sdf_calls), "min_sdf": int(out.min_sdf_calls),
+                "total_pixels": int(out.total_pixels)}
+
+    def selftest_hypot(self, xyz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(a), np.float64)
+        N.check(self._h, N.lib().rm_selftest_hypot(self._h, _ptr(a), len(a), _ptr(out)))
+        return out
+
+
+def camera_from_angles(pitch, yaw):
+    rot = np.zeros(9, np.float32)
+    org = np.zeros(3, np.float32)
+    rc = N.lib().rm_camera_from_angles(float(pitch), float(yaw), _ptr(rot), _ptr(org))
+    if rc != N.RM_OK:
+        raise N.RmError(rc, "rm_camera_from_angles")
+    return rot, org
+
+
+def partition_rows(height, n_workers, i):
+    """main.ts:444-449."""
+    a, b = C.c_int32(0), C.c_int32(0)
+    rc = N.lib().rm_partition_rows(int(height), int(n_workers), int(i), C.byref(a), C.byref(b))
+    if rc != N.RM_OK:
+        raise N.RmError(rc, "rm_partition_rows")
+    return a.value, b.value

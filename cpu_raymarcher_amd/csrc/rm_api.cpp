@@ -1,0 +1,536 @@
+// rm_api.cpp -- the C ABI of include/rm_raymarch.h on top of the HIP kernels.
+//
+// Host side of the tile dispatch (reference src/workers/raymarchWorker.ts:33-92): a job
+// names (preset, accel, camera angles, row range); the ctx keeps the built scene resident
+// in HBM and rebuilds it only when (preset, accel) changes -- the reference rebuilds it
+// twice per tile per frame (scene.ts:24-29 then raymarchWorker.ts:38).
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rm_raymarch.h"
+#include "rm_kernels.h"
+#include "rm_scene_host.h"
+
+namespace {
+
+struct DeviceScene {
+    RmSphere *spheres = nullptr;
+    double *radii = nullptr;
+    RmBvhNode *bvh = nullptr;
+    int32_t *bvh_prims = nullptr;
+    RmOctNode *oct = nullptr;
+    int32_t *oct_prims = nullptr;
+};
+
+}  // namespace
+
+struct rm_ctx {
+    int device = -1;
+    bool has_device = false;
+    std::string err = "";
+    hipStream_t stream = nullptr;  // for the host-buffer entry points
+
+    bool have_scene = false;
+    bool scene_is_uploaded = false;  // active scene came from rm_scene_from_spheres
+    int scene_preset = 0;
+    rmh::HostScene host;
+    DeviceScene dev;
+
+    bool have_uploaded = false;  // sphere list kept for accel changes by later jobs
+    std::vector<float> up_centers;
+    std::vector<double> up_radii;
+
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    RmDiagDevice *d_diag = nullptr;
+    float light[3] = {0, 0, 0};
+
+    int64_t opt_tile_w = 8;
+    int64_t opt_filter = 0;
+    int64_t opt_lds = 0;
+};
+
+namespace {
+
+int fail(rm_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, RM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RM_HIP(ctx, call)                                       \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+void free_device_scene(rm_ctx *ctx) {
+    if (!ctx->has_device) return;
+    DeviceScene &d = ctx->dev;
+    (void)hipFree(d.spheres);
+    (void)hipFree(d.radii);
+    (void)hipFree(d.bvh);
+    (void)hipFree(d.bvh_prims);
+    (void)hipFree(d.oct);
+    (void)hipFree(d.oct_prims);
+    d = DeviceScene();
+}
+
+template <typename T>
+int upload_vec(rm_ctx *ctx, const std::vector<T> &v, T **out) {
+    *out = nullptr;
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    RM_HIP(ctx, hipMalloc(reinterpret_cast<void **>(out), bytes));
+    if (!v.empty()) RM_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RM_OK;
+}
+
+int upload_scene(rm_ctx *ctx) {
+    if (!ctx->has_device) return RM_OK;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());  // nothing may still read the old tables
+    free_device_scene(ctx);
+    int rc;
+    if ((rc = upload_vec(ctx, ctx->host.spheres, &ctx->dev.spheres))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.radii, &ctx->dev.radii))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.bvh, &ctx->dev.bvh))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.bvh_prims, &ctx->dev.bvh_prims))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct, &ctx->dev.oct))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct_prims, &ctx->dev.oct_prims))) return rc;
+    return RM_OK;
+}
+
+int set_scene(rm_ctx *ctx, const float *centers, const double *radii, int n, int accel, bool uploaded, int preset) {
+    std::string err;
+    rmh::HostScene hs;
+    if (!rmh::build_scene(hs, centers, radii, n, accel, err)) {
+        const bool unsupported = err.find("BVH leaf") != std::string::npos;
+        return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
+    }
+    hs.preset = preset;
+    ctx->host = std::move(hs);
+    ctx->have_scene = true;
+    ctx->scene_is_uploaded = uploaded;
+    ctx->scene_preset = preset;
+    return upload_scene(ctx);
+}
+
+int clamp_preset(int idx) { return idx < 0 ? 0 : (idx > rmh::kPresetCount - 1 ? rmh::kPresetCount - 1 : idx); }
+int norm_accel(int a) { return (a == RM_ACCEL_OCTREE || a == RM_ACCEL_BVH) ? a : RM_ACCEL_NONE; }
+
+// makes the scene named by the job the active one (raymarchWorker.ts:37-38)
+int ensure_scene(rm_ctx *ctx, int32_t preset_index, int32_t accel_in) {
+    const int accel = norm_accel(accel_in);
+    if (preset_index == RM_SCENE_UPLOADED) {
+        if (!ctx->have_uploaded) return fail(ctx, RM_E_NO_SCENE, "no scene uploaded with rm_scene_from_spheres");
+        if (ctx->have_scene && ctx->scene_is_uploaded && ctx->host.accel == accel) return RM_OK;
+        return set_scene(ctx, ctx->up_centers.data(), ctx->up_radii.data(), static_cast<int>(ctx->up_radii.size()),
+                         accel, true, RM_SCENE_UPLOADED);
+    }
+    const int preset = clamp_preset(preset_index);
+    if (ctx->have_scene && !ctx->scene_is_uploaded && ctx->scene_preset == preset && ctx->host.accel == accel)
+        return RM_OK;
+    std::vector<float> c;
+    std::vector<double> r;
+    if (!rmh::preset_spheres(preset, c, r))
+        return fail(ctx, RM_E_UNSUPPORTED, "scene preset " + std::to_string(preset) +
+                                               " uses non-sphere primitives or SDF operators (not on the native path)");
+    return set_scene(ctx, c.data(), r.data(), static_cast<int>(r.size()), accel, false, preset);
+}
+
+int ensure_scratch(rm_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return RM_OK;
+    if (ctx->scratch) {
+        RM_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    RM_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return RM_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
+    if (!job) return fail(ctx, RM_E_INVALID, "null job");
+    if (job->height <= 0 || job->width < 0) return fail(ctx, RM_E_INVALID, "width must be >= 0 and height > 0");
+    if (!std::isfinite(job->camera_pitch) || !std::isfinite(job->camera_yaw))
+        return fail(ctx, RM_E_INVALID, "non-finite camera angle");
+    if (job->algorithm != RM_ALG_SPHERE_TRACER)
+        return fail(ctx, RM_E_UNSUPPORTED, "only the sphere tracer is implemented natively");
+    int rc = ensure_scene(ctx, job->scene_preset_index, job->acceleration_structure);
+    if (rc) return rc;
+    std::memset(&p, 0, sizeof p);
+    p.width = job->width;
+    p.height = job->height;
+    p.y_start = job->y_start;
+    p.y_end = job->y_end;
+    rmh::camera_from_angles(job->camera_pitch, job->camera_yaw, p.rot, p.origin);
+    std::memcpy(p.light, ctx->light, sizeof p.light);
+    p.n_prims = static_cast<int32_t>(ctx->host.spheres.size());
+    p.accel = ctx->host.accel;
+    p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
+    p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());
+    p.tile_w = static_cast<int32_t>(ctx->opt_tile_w);
+    p.nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
+    p.filter = static_cast<int32_t>(ctx->opt_filter);
+    p.spheres = ctx->dev.spheres;
+    p.radii = ctx->dev.radii;
+    p.bvh = ctx->dev.bvh;
+    p.bvh_prims = ctx->dev.bvh_prims;
+    p.oct = ctx->dev.oct;
+    p.oct_prims = ctx->dev.oct_prims;
+    return RM_OK;
+}
+
+int norm_shader(int s) { return (s >= RM_SHADE_NORMAL && s <= RM_SHADE_ITERATION_HEATMAP) ? s : RM_SHADE_NORMAL; }
+
+}  // namespace
+
+extern "C" {
+
+const char *rm_version(void) { return "cpu-raymarcher_amd 0.1 (gfx950)"; }
+
+int rm_create(int device, rm_ctx **out) {
+    if (!out) return RM_E_INVALID;
+    *out = nullptr;
+    rm_ctx *ctx = new (std::nothrow) rm_ctx();
+    if (!ctx) return RM_E_NOMEM;
+    rmh::phong_light_dir(ctx->light);
+    if (device >= 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || device >= count) {
+            delete ctx;
+            return RM_E_NO_DEVICE;
+        }
+        e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
+        if (e != hipSuccess) {
+            delete ctx;
+            return RM_E_HIP;
+        }
+        ctx->device = device;
+        ctx->has_device = true;
+    }
+    *out = ctx;
+    return RM_OK;
+}
+
+void rm_destroy(rm_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->has_device) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        free_device_scene(ctx);
+        (void)hipFree(ctx->scratch);
+        (void)hipFree(ctx->d_diag);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char *rm_last_error(const rm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rm_algorithm_from_string(const char *s) {
+    if (!s) return RM_ALG_SPHERE_TRACER;
+    if (!std::strcmp(s, "fixed-step")) return RM_ALG_FIXED_STEP;
+    if (!std::strcmp(s, "adaptive-step")) return RM_ALG_ADAPTIVE_STEP;
+    if (!std::strcmp(s, "adaptive-step-v2")) return RM_ALG_ADAPTIVE_STEP_V2;
+    if (!std::strcmp(s, "adaptive-step-v3")) return RM_ALG_ADAPTIVE_STEP_V3;
+    return RM_ALG_SPHERE_TRACER;  // 'sphere-tracer' and the default branch
+}
+
+int rm_accel_from_string(const char *s) {
+    if (s && !std::strcmp(s, "Octree")) return RM_ACCEL_OCTREE;
+    if (s && !std::strcmp(s, "BVH")) return RM_ACCEL_BVH;
+    return RM_ACCEL_NONE;
+}
+
+int rm_shader_from_string(const char *s) {
+    if (s && !std::strcmp(s, "phong")) return RM_SHADE_PHONG;
+    if (s && !std::strcmp(s, "sdf-heatmap")) return RM_SHADE_SDF_HEATMAP;
+    if (s && !std::strcmp(s, "iteration-heatmap")) return RM_SHADE_ITERATION_HEATMAP;
+    return RM_SHADE_NORMAL;
+}
+
+int rm_preset_count(void) { return rmh::kPresetCount; }
+
+int rm_scene_from_preset(rm_ctx *ctx, int32_t preset_index, int32_t accel) {
+    if (!ctx) return RM_E_INVALID;
+    if (preset_index == RM_SCENE_UPLOADED) return fail(ctx, RM_E_INVALID, "not a preset index");
+    // force a rebuild only when something changed
+    return ensure_scene(ctx, preset_index, accel);
+}
+
+int rm_scene_from_spheres(rm_ctx *ctx, const float *centers_xyz, const double *radii, int32_t n, int32_t accel) {
+    if (!ctx) return RM_E_INVALID;
+    if (n < 0 || (n > 0 && (!centers_xyz || !radii))) return fail(ctx, RM_E_INVALID, "bad sphere list");
+    int rc = set_scene(ctx, centers_xyz, radii, n, norm_accel(accel), true, RM_SCENE_UPLOADED);
+    if (rc) return rc;
+    ctx->up_centers.assign(centers_xyz, centers_xyz + 3 * static_cast<size_t>(n));
+    ctx->up_radii.assign(radii, radii + n);
+    ctx->have_uploaded = true;
+    return RM_OK;
+}
+
+int rm_scene_get_info(const rm_ctx *ctx, rm_scene_info *out) {
+    if (!ctx || !out) return RM_E_INVALID;
+    if (!ctx->have_scene) return RM_E_NO_SCENE;
+    std::memset(out, 0, sizeof *out);
+    const rmh::HostScene &h = ctx->host;
+    out->n_prims = static_cast<int32_t>(h.spheres.size());
+    out->accel = h.accel;
+    out->preset_index = ctx->scene_preset;
+    out->bvh_nodes = static_cast<int32_t>(h.bvh.size());
+    out->bvh_leaves = h.bvh_leaves;
+    out->bvh_depth = h.bvh_depth;
+    out->oct_nodes = static_cast<int32_t>(h.oct.size());
+    out->oct_leaves = h.oct_leaves;
+    out->oct_empty_leaves = h.oct_empty;
+    out->oct_max_leaf_prims = h.oct_max_leaf;
+    std::memcpy(out->root_min, h.root_min, sizeof h.root_min);
+    std::memcpy(out->root_max, h.root_max, sizeof h.root_max);
+    out->nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
+    return RM_OK;
+}
+
+int rm_camera_from_angles(double pitch, double yaw, float *rot9, float *origin3) {
+    if (!rot9 || !origin3 || !std::isfinite(pitch) || !std::isfinite(yaw)) return RM_E_INVALID;
+    rmh::camera_from_angles(pitch, yaw, rot9, origin3);
+    return RM_OK;
+}
+
+int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader, void *d_depth, void *d_normal, void *d_sdf,
+                          void *d_iters, void *d_rgba, void *stream) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context: there is no CPU render path");
+    RmRenderParams p;
+    int rc = fill_params(ctx, job, p);
+    if (rc) return rc;
+    p.shader = norm_shader(shader);
+    p.depth = static_cast<uint8_t *>(d_depth);
+    p.normal = static_cast<uint8_t *>(d_normal);
+    p.sdf = static_cast<uint16_t *>(d_sdf);
+    p.iters = static_cast<uint16_t *>(d_iters);
+    p.rgba = static_cast<uint8_t *>(d_rgba);
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, rm_launch_render(p, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_render_tile(rm_ctx *ctx, const rm_job *job, uint8_t *depth, uint8_t *normal, uint16_t *sdf, uint16_t *iters) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context: there is no CPU render path");
+    if (!job) return fail(ctx, RM_E_INVALID, "null job");
+    if (!depth || !normal || !sdf || !iters) return fail(ctx, RM_E_INVALID, "null output buffer");
+    const int64_t rows = job->y_end > job->y_start ? static_cast<int64_t>(job->y_end) - job->y_start : 0;
+    const size_t npx = static_cast<size_t>(rows) * static_cast<size_t>(job->width > 0 ? job->width : 0);
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t o_depth = 0, o_normal = align_up(npx, 256), o_sdf = o_normal + align_up(3 * npx, 256),
+                 o_iters = o_sdf + align_up(2 * npx, 256), total = o_iters + align_up(2 * npx, 256);
+    int rc = ensure_scratch(ctx, total ? total : 256);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    rc = rm_render_tile_device(ctx, job, RM_SHADE_NORMAL, base + o_depth, base + o_normal, base + o_sdf,
+                               base + o_iters, nullptr, ctx->stream);
+    if (rc) return rc;
+    if (npx) {
+        RM_HIP(ctx, hipMemcpyAsync(depth, base + o_depth, npx, hipMemcpyDeviceToHost, ctx->stream));
+        RM_HIP(ctx, hipMemcpyAsync(normal, base + o_normal, 3 * npx, hipMemcpyDeviceToHost, ctx->stream));
+        RM_HIP(ctx, hipMemcpyAsync(sdf, base + o_sdf, 2 * npx, hipMemcpyDeviceToHost, ctx->stream));
+        RM_HIP(ctx, hipMemcpyAsync(iters, base + o_iters, 2 * npx, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_shade_device(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height, const void *d_depth,
+                    const void *d_normal, const void *d_sdf, const void *d_iters, void *d_rgba, void *stream) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (width < 0 || height < 0) return fail(ctx, RM_E_INVALID, "negative size");
+    if (!d_depth || !d_normal || !d_sdf || !d_iters || !d_rgba) return fail(ctx, RM_E_INVALID, "null buffer");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, rm_launch_shade(norm_shader(shader), static_cast<int64_t>(width) * height,
+                                static_cast<const uint8_t *>(d_depth), static_cast<const uint8_t *>(d_normal),
+                                static_cast<const uint16_t *>(d_sdf), static_cast<const uint16_t *>(d_iters),
+                                static_cast<uint8_t *>(d_rgba), ctx->light, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_shade(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height, const uint8_t *depth, const uint8_t *normal,
+             const uint16_t *sdf, const uint16_t *iters, uint8_t *rgba) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (width < 0 || height < 0) return fail(ctx, RM_E_INVALID, "negative size");
+    if (!depth || !normal || !sdf || !iters || !rgba) return fail(ctx, RM_E_INVALID, "null buffer");
+    const size_t npx = static_cast<size_t>(width) * static_cast<size_t>(height);
+    if (!npx) return RM_OK;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t o_depth = 0, o_normal = align_up(npx, 256), o_sdf = o_normal + align_up(3 * npx, 256),
+                 o_iters = o_sdf + align_up(2 * npx, 256), o_rgba = o_iters + align_up(2 * npx, 256),
+                 total = o_rgba + align_up(4 * npx, 256);
+    int rc = ensure_scratch(ctx, total);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    RM_HIP(ctx, hipMemcpyAsync(base + o_depth, depth, npx, hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(base + o_normal, normal, 3 * npx, hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(base + o_sdf, sdf, 2 * npx, hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(base + o_iters, iters, 2 * npx, hipMemcpyHostToDevice, ctx->stream));
+    rc = rm_shade_device(ctx, shader, width, height, base + o_depth, base + o_normal, base + o_sdf, base + o_iters,
+                         base + o_rgba, ctx->stream);
+    if (rc) return rc;
+    RM_HIP(ctx, hipMemcpyAsync(rgba, base + o_rgba, 4 * npx, hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n, rm_diagnostics *out,
+                              void *stream) {
+    if (!ctx || !out) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (n < 0 || (n > 0 && (!d_sdf || !d_iters))) return fail(ctx, RM_E_INVALID, "bad buffers");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RmDiagDevice init;
+    init.total_sdf = 0;
+    init.total_iters = 0;
+    init.max_sdf = 0;
+    init.min_sdf = 0xFFFFFFFFu;
+    RM_HIP(ctx, hipMemcpyAsync(ctx->d_diag, &init, sizeof init, hipMemcpyHostToDevice, st));
+    RM_HIP(ctx, rm_launch_reduce(static_cast<const uint16_t *>(d_sdf), static_cast<const uint16_t *>(d_iters), n,
+                                 ctx->d_diag, st));
+    RmDiagDevice res;
+    RM_HIP(ctx, hipMemcpyAsync(&res, ctx->d_diag, sizeof res, hipMemcpyDeviceToHost, st));
+    RM_HIP(ctx, hipStreamSynchronize(st));
+    out->total_sdf_calls = res.total_sdf;
+    out->total_iterations = res.total_iters;
+    out->max_sdf_calls = res.max_sdf;
+    out->min_sdf_calls = res.min_sdf;
+    out->total_pixels = static_cast<uint64_t>(n);
+    return RM_OK;
+}
+
+int rm_reduce_counters(rm_ctx *ctx, const uint16_t *sdf, const uint16_t *iters, int64_t n, rm_diagnostics *out) {
+    if (!ctx || !out) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (n < 0 || (n > 0 && (!sdf || !iters))) return fail(ctx, RM_E_INVALID, "bad buffers");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = 2 * static_cast<size_t>(n);
+    const size_t o_iters = align_up(bytes, 256);
+    int rc = ensure_scratch(ctx, o_iters + align_up(bytes, 256) + 256);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    if (n) {
+        RM_HIP(ctx, hipMemcpyAsync(base, sdf, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RM_HIP(ctx, hipMemcpyAsync(base + o_iters, iters, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return rm_reduce_counters_device(ctx, base, base + o_iters, n, out, ctx->stream);
+}
+
+int rm_partition_rows(int32_t height, int32_t n_workers, int32_t i, int32_t *y_start, int32_t *y_end) {
+    if (!y_start || !y_end || n_workers <= 0 || height < 0 || i < 0) return RM_E_INVALID;
+    // main.ts:444-449
+    const int64_t rows = (static_cast<int64_t>(height) + n_workers - 1) / n_workers;
+    const int64_t a = static_cast<int64_t>(i) * rows, b = (static_cast<int64_t>(i) + 1) * rows;
+    *y_start = static_cast<int32_t>(a < height ? a : height);
+    *y_end = static_cast<int32_t>(b < height ? b : height);
+    return RM_OK;
+}
+
+int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *dist, uint32_t *count) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (!ctx->have_scene) return fail(ctx, RM_E_NO_SCENE, "no scene set");
+    if (n < 0 || (n > 0 && (!points_xyz || !dist || !count))) return fail(ctx, RM_E_INVALID, "bad buffers");
+    if (!n) return RM_OK;
+    for (int64_t i = 0; i < 3 * n; ++i)
+        if (!std::isfinite(points_xyz[i])) return fail(ctx, RM_E_INVALID, "non-finite point");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t o_dist = align_up(12 * static_cast<size_t>(n), 256), o_cnt = o_dist + align_up(8 * static_cast<size_t>(n), 256);
+    int rc = ensure_scratch(ctx, o_cnt + align_up(4 * static_cast<size_t>(n), 256));
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    RmRenderParams p;
+    std::memset(&p, 0, sizeof p);
+    p.n_prims = static_cast<int32_t>(ctx->host.spheres.size());
+    p.accel = ctx->host.accel;
+    p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
+    p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());
+    p.filter = static_cast<int32_t>(ctx->opt_filter);
+    p.tile_w = 8;
+    p.spheres = ctx->dev.spheres;
+    p.radii = ctx->dev.radii;
+    p.bvh = ctx->dev.bvh;
+    p.bvh_prims = ctx->dev.bvh_prims;
+    p.oct = ctx->dev.oct;
+    p.oct_prims = ctx->dev.oct_prims;
+    RM_HIP(ctx, hipMemcpyAsync(base, points_xyz, 12 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(ctx, rm_launch_distance(p, reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_dist),
+                                   reinterpret_cast<uint32_t *>(base + o_cnt), ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(dist, base + o_dist, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(count, base + o_cnt, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (n < 0 || (n > 0 && (!xyz || !out))) return fail(ctx, RM_E_INVALID, "bad buffers");
+    if (!n) return RM_OK;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t o_out = align_up(12 * static_cast<size_t>(n), 256);
+    int rc = ensure_scratch(ctx, o_out + 8 * static_cast<size_t>(n));
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    RM_HIP(ctx, hipMemcpyAsync(base, xyz, 12 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+    RM_HIP(ctx, rm_launch_hypot(reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_out),
+                                ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(out, base + o_out, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return RM_E_INVALID;
+    if (!std::strcmp(key, "tile_w")) {
+        if (value != 8 && value != 16 && value != 32 && value != 64) return fail(ctx, RM_E_INVALID, "tile_w must be 8, 16, 32 or 64");
+        ctx->opt_tile_w = value;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "filter")) {
+        ctx->opt_filter = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "nodes_in_lds")) {
+        ctx->opt_lds = value ? 1 : 0;
+        return RM_OK;
+    }
+    return fail(ctx, RM_E_INVALID, std::string("unknown option ") + key);
+}
+
+int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
+    if (!ctx || !key || !value) return RM_E_INVALID;
+    if (!std::strcmp(key, "tile_w")) *value = ctx->opt_tile_w;
+    else if (!std::strcmp(key, "filter")) *value = ctx->opt_filter;
+    else if (!std::strcmp(key, "nodes_in_lds")) *value = ctx->opt_lds;
+    else return RM_E_INVALID;
+    return RM_OK;
+}
+
+}  // extern "C"

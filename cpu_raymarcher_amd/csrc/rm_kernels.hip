@@ -1,0 +1,570 @@
+// rm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the sphere-tracing render path.
+//
+// One ray per lane.  A 64-lane wavefront owns a tile_w x (64 / tile_w) pixel tile, a
+// 256-thread workgroup four such tiles stacked vertically.  There is no dense contraction
+// anywhere on this path, so no MFMA: the work is FP64 VALU (the reference computes in JS
+// doubles) with binary32 rounding exactly where the reference stores into Float32Array,
+// plus f32 compares for box tests.  Build with -ffp-contract=off: JS never fuses a*b+c.
+//
+// Reference functions restated here (paths relative to the reference's src/):
+//   Raymarcher.runRaymarcher / getSceneDistance / getNormal   cpu_algorithms/raymarcher.ts:46-135
+//   SphereTracer.rayMarch                                     cpu_algorithms/sphereTracer.ts:15-83
+//   Scene.getDistance                                         util/scene.ts:144-190
+//   Primitive.sdf / Sphere.localSdf                           util/primitives/primitive.ts:33-39, sphere.ts:12-14
+//   BVH.getPrimitivesAt / findRayIntersections / onRayMarch*  acceleration_structures/bvh.ts:95-240
+//   BoundingBox.contains / intersectRay                       acceleration_structures/boundingBox.ts:15-21,69-105
+//   Octree.findNode / marchRay / intersectRayBox              acceleration_structures/octree.ts:195-294
+//   ShadingModel.shade (4 models)                             util/shading_models/*.ts
+//   diagnostics                                               main.ts:528-548
+#include <hip/hip_runtime.h>
+
+#include "rm_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ number semantics
+
+__device__ __forceinline__ float to_f32(double v) { return static_cast<float>(v); }  // Float32Array store
+
+// Uint8ClampedArray store: NaN -> 0, clamp, round half to even (v_rndne_f64)
+__device__ __forceinline__ uint8_t u8clamp(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 255.0) return 255;
+    return static_cast<uint8_t>(__builtin_rint(v));
+}
+
+// V8 Math.hypot(x, y, z) for finite binary32-valued inputs: scale by the largest
+// magnitude, Kahan-sum the squares in argument order, sqrt, rescale.  The first Kahan
+// step is folded by hand (sum = 0, compensation = 0 make it exact).
+__device__ __forceinline__ double hypot3(float lx, float ly, float lz) {
+    const double ax = __builtin_fabs(static_cast<double>(lx));
+    const double ay = __builtin_fabs(static_cast<double>(ly));
+    const double az = __builtin_fabs(static_cast<double>(lz));
+    double big = ax > ay ? ax : ay;
+    big = az > big ? az : big;
+    if (big == 0.0) return 0.0;
+    const double nx = ax / big, ny = ay / big, nz = az / big;
+    double sum = nx * nx;
+    const double sy = ny * ny;  // summand - compensation(=0)
+    double next = sum + sy;
+    const double comp = (next - sum) - sy;
+    sum = next;
+    const double sz = nz * nz - comp;
+    sum = sum + sz;
+    return __builtin_sqrt(sum) * big;
+}
+
+struct Vec3f {
+    float x, y, z;
+};
+
+// Primitive.sdf for a translation-only world->local transform: transformMat4 reduces to
+// f32(f64(p - c)), which equals the binary32 subtraction (double rounding is innocuous
+// for +,- when the wide format has >= 2p+2 bits), then Sphere.localSdf.
+__device__ __forceinline__ double sphere_sdf(const RmSphere &s, double radius, const Vec3f &p) {
+    return hypot3(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
+}
+
+// Math.min(candidate, closest) -- operands are never NaN here (inputs validated finite)
+__device__ __forceinline__ double min_dist(double candidate, double closest) {
+    return candidate < closest ? candidate : closest;
+}
+
+__device__ __forceinline__ bool box_contains(const float lo[3], const float hi[3], const Vec3f &p) {
+    return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
+}
+
+// ------------------------------------------------------------------ Scene.getDistance
+
+// scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
+__device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
+    double closest = RM_MAX_DIST;
+    for (int i = 0; i < P.n_prims; ++i) closest = min_dist(sphere_sdf(P.spheres[i], P.radii[i], p), closest);
+    count += static_cast<uint32_t>(P.n_prims);
+    return closest;
+}
+
+// scene.ts:167-181 with BVH.getPrimitivesAt (bvh.ts:95-121): union of the primitives of
+// every leaf whose box contains p (a primitive lives in exactly one leaf), else all.
+__device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
+    double closest = RM_MAX_DIST;
+    uint32_t found = 0;
+    int i = 0;
+    const int n = P.bvh_nodes;
+    while (i < n) {
+        const RmBvhNode node = P.bvh[i];
+        if (!box_contains(node.lo, node.hi, p)) {
+            i = node.skip;
+            continue;
+        }
+        if (node.leaf < 0) {
+            i = i + 1;
+            continue;
+        }
+        const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
+        for (int k = 0; k < cnt; ++k) {
+            const int id = P.bvh_prims[first + k];
+            closest = min_dist(sphere_sdf(P.spheres[id], P.radii[id], p), closest);
+        }
+        found += static_cast<uint32_t>(cnt);
+        i = node.skip;
+    }
+    if (found == 0) return all_prims_distance(P, p, count);
+    count += found;
+    return closest;
+}
+
+// Octree.findNode (octree.ts:223-248): -1 when p is outside the root cube.  Children tile
+// their parent at the f32 centre and `contains` is inclusive, so the first child (index
+// order x + 2y + 4z) that contains p takes the low half on every axis where p <= centre.
+__device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
+    const RmOctNode *nodes = P.oct;
+    if (!box_contains(nodes[0].lo, nodes[0].hi, p)) return -1;
+    int i = 0;
+    for (;;) {
+        const int first = nodes[i].first_child;
+        if (first < 0) return i;
+        const float cx = nodes[first].hi[0], cy = nodes[first].hi[1], cz = nodes[first].hi[2];
+        i = first + (p.x > cx ? 1 : 0) + (p.y > cy ? 2 : 0) + (p.z > cz ? 4 : 0);
+    }
+}
+
+// scene.ts:148-166 given the node findNode returned
+__device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec3f &p, uint32_t &count) {
+    if (node < 0) return all_prims_distance(P, p, count);  // outside the cube: scene.ts:166,183-189
+    const RmOctNode nd = P.oct[node];
+    double closest = RM_MAX_DIST;
+    if (nd.prim_count > 0) {
+        for (int k = 0; k < nd.prim_count; ++k) {
+            const int id = P.oct_prims[nd.prim_first + k];
+            closest = min_dist(sphere_sdf(P.spheres[id], P.radii[id], p), closest);
+        }
+        count += static_cast<uint32_t>(nd.prim_count);
+    } else if (nd.is_empty) {
+        closest = min_dist(nd.min_distance * 0.99, closest);  // Math.min(closest, minDistance * safety)
+    }
+    return closest;
+}
+
+template <int ACCEL>
+__device__ __forceinline__ double scene_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
+    if (ACCEL == 2) return bvh_distance(P, p, count);
+    if (ACCEL == 1) return oct_node_distance(P, oct_find(P, p), p, count);
+    return all_prims_distance(P, p, count);
+}
+
+// ------------------------------------------------------------------ BVH ray intervals
+
+struct Ray {
+    Vec3f o, d;
+};
+
+// BoundingBox.intersectRay (boundingBox.ts:69-105); false = null
+__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const Ray &r, double &tEnter,
+                                     double &tExit) {
+    double tMin = -__builtin_inf(), tMax = __builtin_inf();
+    const float o[3] = {r.o.x, r.o.y, r.o.z};
+    const float d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (__builtin_fabs(static_cast<double>(d[a])) < 1e-10) {
+            if (o[a] < lo[a] || o[a] > hi[a]) return false;
+        } else {
+            const double inv = 1.0 / static_cast<double>(d[a]);
+            double t0 = (static_cast<double>(lo[a]) - static_cast<double>(o[a])) * inv;
+            double t1 = (static_cast<double>(hi[a]) - static_cast<double>(o[a])) * inv;
+            if (t0 > t1) {
+                const double t = t0;
+                t0 = t1;
+                t1 = t;
+            }
+            tMin = tMin > t0 ? tMin : t0;  // Math.max; no NaN possible (|d| >= 1e-10)
+            tMax = tMax < t1 ? tMax : t1;  // Math.min
+            if (tMin > tMax) return false;
+        }
+    }
+    tEnter = tMin;
+    tExit = tMax;
+    return true;
+}
+
+struct Interval {
+    double tEnter, tExit;
+    int ord;  // node index == position in the traversal order of bvh.ts:136-173
+};
+
+// The reference materialises every leaf interval of the ray, stable-sorts them by tEnter
+// (bvh.ts:126-178) and walks the list with an index (bvh.ts:204-240).  This returns the
+// element that follows key (keyT, keyOrd) in exactly that order -- ascending tEnter, ties
+// in traversal order -- by one stackless traversal, so no per-ray list is stored.
+__device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, double keyT, int keyOrd, Interval &out) {
+    bool have = false;
+    int i = 0;
+    const int n = P.bvh_nodes;
+    while (i < n) {
+        const RmBvhNode node = P.bvh[i];
+        double tE, tX;
+        if (!slab(node.lo, node.hi, r, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
+            i = node.skip;
+            continue;
+        }
+        if (node.leaf < 0) {
+            i = i + 1;
+            continue;
+        }
+        if ((node.leaf & 0xFF) > 0) {  // bvh.ts:165
+            const double cE = tE > 0.0 ? tE : 0.0;                  // Math.max(tEnter, tMin = 0)
+            const double cX = tX < RM_MAX_DIST ? tX : RM_MAX_DIST;  // Math.min(tExit, tMax = 10)
+            const bool after = cE > keyT || (cE == keyT && i > keyOrd);
+            const bool better = !have || cE < out.tEnter;  // equal tEnter: earlier node wins, seen first
+            if (after && better) {
+                out.tEnter = cE;
+                out.tExit = cX;
+                out.ord = i;
+                have = true;
+            }
+        }
+        i = node.skip;
+    }
+    return have;
+}
+
+// ------------------------------------------------------------------ Octree empty-space skip
+
+// Octree.marchRay (octree.ts:252-278) for the node that contains the current point.
+// intersectRayBox (octree.ts:195-220) has no zero-direction guard and stores t0/t1 in a
+// Float32Array; 0 * Infinity = NaN then flows through Math.max/min (NaN-propagating) and
+// every comparison with NaN is false, which ends in "return 0".
+__device__ double oct_skip(const RmOctNode &nd, const Ray &r, double t) {
+    if (!nd.is_empty) return 0.0;
+    const float o[3] = {r.o.x, r.o.y, r.o.z};
+    const float d[3] = {r.d.x, r.d.y, r.d.z};
+    float tn[3], tf[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double inv = 1.0 / static_cast<double>(d[a]);
+        double t0 = (static_cast<double>(nd.lo[a]) - static_cast<double>(o[a])) * inv;
+        double t1 = (static_cast<double>(nd.hi[a]) - static_cast<double>(o[a])) * inv;
+        if (inv < 0.0) {
+            const double s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        tn[a] = to_f32(t0);
+        tf[a] = to_f32(t1);
+    }
+    // JS: tEnter = Math.max(tMin[0..2]), tExit = Math.min(tMax[0..2]) are NaN when any
+    // operand is; `tEnter > tExit || tExit < 0` is false whenever a NaN takes part, and only
+    // tExit is used afterwards, so a NaN tEnter is ignored while a NaN tExit ends in 0.
+    if (tf[0] != tf[0] || tf[1] != tf[1] || tf[2] != tf[2]) return 0.0;
+    float x = tf[0] < tf[1] ? tf[0] : tf[1];
+    x = tf[2] < x ? tf[2] : x;
+    const double tExit = x;
+    if (!(tn[0] != tn[0] || tn[1] != tn[1] || tn[2] != tn[2])) {
+        float e = tn[0] > tn[1] ? tn[0] : tn[1];
+        e = tn[2] > e ? tn[2] : e;
+        if (static_cast<double>(e) > tExit) return 0.0;
+    }
+    if (tExit < 0.0) return 0.0;
+    double toExit = tExit - t;
+    toExit = toExit > 0.0 ? toExit : 0.0;  // Math.max(0, .)
+    const double cap = nd.min_distance * 0.99;
+    double step = toExit < cap ? toExit : cap;
+    step = step > 0.0 ? step : 0.0;
+    return step > 0.0 ? step + 0.001 : 0.0;
+}
+
+// ------------------------------------------------------------------ shading
+
+// ShadingModel.shade for one pixel.  Heatmaps and Normal are pure integer; Phong follows
+// phongModel.ts:33-72 in double with f32 stores.
+__device__ uchar4 shade_pixel(int shader, uint8_t depth, uint8_t n0, uint8_t n1, uint8_t n2, uint16_t sdf,
+                              uint16_t iters, const float light[3]) {
+    if (shader == 2 || shader == 3) {
+        const uint32_t c = shader == 2 ? sdf : iters;
+        const uint32_t k = (c * 5u) & 255u;                       // counter * 5 % 256
+        const uint32_t r = 2u * k < 255u ? 2u * k : 255u;          // Math.min(2k, 255)
+        const uint32_t g = 512u - 2u * k < 255u ? 512u - 2u * k : 255u;  // Math.min(-2k + 512, 255)
+        return make_uchar4(static_cast<uint8_t>(r), static_cast<uint8_t>(g), 0, 255);
+    }
+    if (shader == 1) {
+        if (depth >= 255) return make_uchar4(10, 10, 20, 255);
+        float nx = to_f32(static_cast<double>(n0) / 127.5 - 1.0);
+        float ny = to_f32(static_cast<double>(n1) / 127.5 - 1.0);
+        float nz = to_f32(static_cast<double>(n2) / 127.5 - 1.0);
+        double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
+        if (len > 0) len = 1 / __builtin_sqrt(len);
+        nx = to_f32(nx * len);
+        ny = to_f32(ny * len);
+        nz = to_f32(nz * len);
+        const double ndl = static_cast<double>(nx) * light[0] + static_cast<double>(ny) * light[1] +
+                           static_cast<double>(nz) * light[2];
+        const double diffuse = ndl > 0.0 ? ndl : 0.0;
+        const double k2 = 2 * ndl;
+        float rx = to_f32(nx * k2), ry = to_f32(ny * k2), rz = to_f32(nz * k2);
+        rx = to_f32(static_cast<double>(rx) - light[0]);
+        ry = to_f32(static_cast<double>(ry) - light[1]);
+        rz = to_f32(static_cast<double>(rz) - light[2]);
+        double rl = static_cast<double>(rx) * rx + static_cast<double>(ry) * ry + static_cast<double>(rz) * rz;
+        if (rl > 0) rl = 1 / __builtin_sqrt(rl);
+        rz = to_f32(rz * rl);
+        const double vdr = static_cast<double>(rz);  // dot((0,0,1), reflect)
+        const double base = vdr > 0.0 ? vdr : 0.0;
+        // Math.pow(base, 32): five exact-order squarings would differ from V8's pow in the
+        // last bits; either way the byte below is within 1 LSB (tolerance of the contract)
+        const double spec = 0.5 * pow(base, 32.0);
+        double inten = 0.1 + diffuse + spec;
+        inten = inten < 1.0 ? inten : 1.0;
+        const double color = 255 * inten * (1 - static_cast<double>(depth) / 255);
+        const uint8_t c = u8clamp(color);
+        return make_uchar4(c, c, c, 255);
+    }
+    return make_uchar4(n0, n1, n2, 255);
+}
+
+// ------------------------------------------------------------------ the render kernel
+
+template <int ACCEL>
+__device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, double depth, uint32_t &count,
+                                   uint8_t nb[3]) {
+    // raymarcher.ts:94-105
+    Vec3f hit;
+    hit.x = to_f32(static_cast<double>(ray.o.x) + static_cast<double>(ray.d.x) * depth);
+    hit.y = to_f32(static_cast<double>(ray.o.y) + static_cast<double>(ray.d.y) * depth);
+    hit.z = to_f32(static_cast<double>(ray.o.z) + static_cast<double>(ray.d.z) * depth);
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (!(depth >= RM_MAX_DIST)) {
+        // raymarcher.ts:123-135 getNormal
+        const double d0 = scene_distance<ACCEL>(P, hit, count);
+        Vec3f q = hit;
+        q.x = to_f32(static_cast<double>(hit.x) - 0.01);
+        nx = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        q = hit;
+        q.y = to_f32(static_cast<double>(hit.y) - 0.01);
+        ny = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        q = hit;
+        q.z = to_f32(static_cast<double>(hit.z) - 0.01);
+        nz = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
+        if (len > 0) len = 1 / __builtin_sqrt(len);
+        nx = to_f32(nx * len);
+        ny = to_f32(ny * len);
+        nz = to_f32(nz * len);
+    }
+    nb[0] = u8clamp((static_cast<double>(nx) + 1) * 0.5 * 255);
+    nb[1] = u8clamp((static_cast<double>(ny) + 1) * 0.5 * 255);
+    nb[2] = u8clamp((static_cast<double>(nz) + 1) * 0.5 * 255);
+    return depth;
+}
+
+// SphereTracer.rayMarch (sphereTracer.ts:15-83)
+template <int ACCEL>
+__device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
+    double t = 0.0;
+    Interval cur;
+    bool haveCur = false;
+    if (ACCEL == 2) {
+        haveCur = bvh_next_interval(P, ray, -__builtin_inf(), -1, cur);  // onRayMarchStart
+        if (!haveCur) return RM_MAX_DIST;                                // bvh.ts:190-192
+    }
+    for (int i = 0; i < RM_MAX_STEPS; ++i) {
+        Vec3f p;
+        p.x = to_f32(static_cast<double>(ray.o.x) + static_cast<double>(ray.d.x) * t);
+        p.y = to_f32(static_cast<double>(ray.o.y) + static_cast<double>(ray.d.y) * t);
+        p.z = to_f32(static_cast<double>(ray.o.z) + static_cast<double>(ray.d.z) * t);
+        int onode = -1;
+        if (ACCEL == 2) {
+            // BVH.onRayMarchStep (bvh.ts:204-240)
+            double skip = 0.0;
+            if (!haveCur) return RM_MAX_DIST;  // currentIntervalIdx >= length
+            if (t < cur.tEnter) skip = cur.tEnter - t;
+            else if (t > cur.tExit) {
+                const Interval prev = cur;
+                haveCur = bvh_next_interval(P, ray, prev.tEnter, prev.ord, cur);  // idx++
+                if (!haveCur) return RM_MAX_DIST;
+                if (cur.tEnter > t) skip = cur.tEnter - t;
+            }
+            if (skip > 0.0) {
+                t += skip;
+                if (t > RM_MAX_DIST) break;
+                continue;
+            }
+        } else if (ACCEL == 1) {
+            onode = oct_find(P, p);  // marchRay recomputes this same point
+            if (onode >= 0) {
+                const double skip = oct_skip(P.oct[onode], ray, t);
+                if (skip > 0.0) {
+                    t += skip;
+                    if (t > RM_MAX_DIST) break;
+                    continue;
+                }
+            }
+        }
+        double dist;
+        if (ACCEL == 1) dist = oct_node_distance(P, onode, p, count);
+        else dist = scene_distance<ACCEL>(P, p, count);
+        t += dist;
+        iters += 1;
+        if (dist < RM_EPSILON) break;
+        if (t > RM_MAX_DIST) break;
+    }
+    return t;
+}
+
+template <int ACCEL>
+__global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
+    // wave tile: tile_w x (64 / tile_w); four waves stacked vertically per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tw = P.tile_w, th = 64 / tw;
+    const int tiles_x = (P.width + tw - 1) / tw;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int x = bx * tw + (lane % tw);
+    const int row = by * (4 * th) + wave * th + (lane / tw);  // tile-local row
+    const int rows = P.y_end - P.y_start;
+    if (x >= P.width || row >= rows) return;
+    const int y = P.y_start + row;
+    const size_t idx = static_cast<size_t>(row) * P.width + x;
+
+    // raymarcher.ts:73,83-88
+    const double v = (static_cast<double>(y) / static_cast<double>(P.height) - 0.5) * 2.0;
+    const double u = (static_cast<double>(x) / static_cast<double>(P.width) - 0.5) * 2.0;
+    const double ax = to_f32(u), ay = to_f32(v), az = -1.0;
+    float dx = to_f32(ax * P.rot[0] + ay * P.rot[3] + az * P.rot[6]);
+    float dy = to_f32(ax * P.rot[1] + ay * P.rot[4] + az * P.rot[7]);
+    float dz = to_f32(ax * P.rot[2] + ay * P.rot[5] + az * P.rot[8]);
+    double len = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
+    if (len > 0) len = 1 / __builtin_sqrt(len);
+    Ray ray;
+    ray.d.x = to_f32(dx * len);
+    ray.d.y = to_f32(dy * len);
+    ray.d.z = to_f32(dz * len);
+    ray.o.x = P.origin[0];
+    ray.o.y = P.origin[1];
+    ray.o.z = P.origin[2];
+
+    uint32_t count = 0, iters = 0;
+    const double depth = ray_march<ACCEL>(P, ray, count, iters);
+    uint8_t nb[3];
+    normal_and_store<ACCEL>(P, ray, depth, count, nb);
+    const uint8_t db = u8clamp(depth);
+    const uint16_t c16 = static_cast<uint16_t>(count & 0xFFFFu);  // Uint16Array += wraps
+    const uint16_t i16 = static_cast<uint16_t>(iters & 0xFFFFu);
+    if (P.depth) P.depth[idx] = db;
+    if (P.normal) {
+        P.normal[3 * idx] = nb[0];
+        P.normal[3 * idx + 1] = nb[1];
+        P.normal[3 * idx + 2] = nb[2];
+    }
+    if (P.sdf) P.sdf[idx] = c16;
+    if (P.iters) P.iters[idx] = i16;
+    if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light);
+}
+
+// ------------------------------------------------------------------ small kernels
+
+__global__ __launch_bounds__(256) void shade_kernel(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
+                                                    const uint16_t *sdf, const uint16_t *iters, uchar4 *rgba, float l0,
+                                                    float l1, float l2) {
+    const float light[3] = {l0, l1, l2};
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        rgba[i] = shade_pixel(shader, depth[i], normal[3 * i], normal[3 * i + 1], normal[3 * i + 2], sdf[i], iters[i],
+                              light);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const uint16_t *iters, int64_t n,
+                                                     RmDiagDevice *acc) {
+    unsigned long long s = 0, it = 0;
+    unsigned int mx = 0, mn = 0xFFFFFFFFu;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const unsigned int c = sdf[i];
+        s += c;
+        it += iters[i];
+        mx = c > mx ? c : mx;
+        mn = c < mn ? c : mn;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        it += __shfl_down(it, off);
+        const unsigned int omx = __shfl_down(mx, off), omn = __shfl_down(mn, off);
+        mx = omx > mx ? omx : mx;
+        mn = omn < mn ? omn : mn;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc->total_sdf, s);
+        atomicAdd(&acc->total_iters, it);
+        atomicMax(&acc->max_sdf, mx);
+        atomicMin(&acc->min_sdf, mn);
+    }
+}
+
+template <int ACCEL>
+__global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
+                                                       uint32_t *count) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    Vec3f p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    uint32_t c = 0;
+    dist[i] = scene_distance<ACCEL>(P, p, c);
+    count[i] = c;
+}
+
+__global__ __launch_bounds__(256) void hypot_kernel(const float *xyz, int64_t n, double *out) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    out[i] = hypot3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------- launchers
+
+hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
+    const int rows = p.y_end - p.y_start;
+    if (rows <= 0 || p.width <= 0) return hipSuccess;
+    const int tw = p.tile_w, th = 64 / tw;
+    const int tiles_x = (p.width + tw - 1) / tw;
+    const int tiles_y = (rows + 4 * th - 1) / (4 * th);
+    const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
+    if (p.accel == 2) hipLaunchKernelGGL(render_kernel<2>, grid, block, 0, stream, p);
+    else if (p.accel == 1) hipLaunchKernelGGL(render_kernel<1>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(render_kernel<0>, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal, const uint16_t *sdf,
+                           const uint16_t *iters, uint8_t *rgba, const float light[3], hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(shade_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, shader, n, depth,
+                       normal, sdf, iters, reinterpret_cast<uchar4 *>(rgba), light[0], light[1], light[2]);
+    return hipGetLastError();
+}
+
+hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t n, RmDiagDevice *acc,
+                            hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sdf, iters, n, acc);
+    return hipGetLastError();
+}
+
+hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int64_t n, double *dist, uint32_t *count,
+                              hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+    if (p.accel == 2) hipLaunchKernelGGL(distance_kernel<2>, grid, block, 0, stream, p, points, n, dist, count);
+    else if (p.accel == 1) hipLaunchKernelGGL(distance_kernel<1>, grid, block, 0, stream, p, points, n, dist, count);
+    else hipLaunchKernelGGL(distance_kernel<0>, grid, block, 0, stream, p, points, n, dist, count);
+    return hipGetLastError();
+}
+
+hipError_t rm_launch_hypot(const float *xyz, int64_t n, double *out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hypot_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, xyz, n, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,404 @@
+// rm_scene_host.cpp -- see rm_scene_host.h.
+//
+// Arithmetic contract: the reference computes in JS doubles and
+// rounds to binary32 wherever it stores into a gl-matrix vector/matrix, so every helper
+// here evaluates in double, one rounding per operation (build with -ffp-contract=off),
+// and narrows to float exactly where the reference stores.
+#include "rm_scene_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace rmh {
+
+namespace {
+
+inline float to_f32(double v) { return static_cast<float>(v); }
+
+// ---- 4x4 helpers on Float32Array-like storage (column-major, gl-matrix 3.x) ----------
+
+struct Mat4 {
+    float m[16];
+    static Mat4 identity() {
+        Mat4 r;
+        for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        return r;
+    }
+};
+
+// mat4.rotateY(out, a, rad) for out != a
+Mat4 rotate_y(const Mat4 &a, double rad) {
+    const double s = std::sin(rad), c = std::cos(rad);
+    Mat4 r = a;
+    for (int k = 0; k < 4; ++k) {
+        const double row0 = a.m[k], row2 = a.m[8 + k];
+        r.m[k] = to_f32(row0 * c - row2 * s);
+        r.m[8 + k] = to_f32(row0 * s + row2 * c);
+    }
+    return r;
+}
+
+// mat4.rotateX(out, a, rad) for out != a
+Mat4 rotate_x(const Mat4 &a, double rad) {
+    const double s = std::sin(rad), c = std::cos(rad);
+    Mat4 r = a;
+    for (int k = 0; k < 4; ++k) {
+        const double row1 = a.m[4 + k], row2 = a.m[8 + k];
+        r.m[4 + k] = to_f32(row1 * c + row2 * s);
+        r.m[8 + k] = to_f32(row2 * c - row1 * s);
+    }
+    return r;
+}
+
+// mat4.translate(out, a, v) for out != a
+Mat4 translate(const Mat4 &a, const float v[3]) {
+    Mat4 r = a;
+    const double x = v[0], y = v[1], z = v[2];
+    for (int k = 0; k < 4; ++k)
+        r.m[12 + k] = to_f32(double(a.m[k]) * x + double(a.m[4 + k]) * y + double(a.m[8 + k]) * z +
+                             double(a.m[12 + k]));
+    return r;
+}
+
+// JS Math.min / Math.max for finite-or-infinite, non-NaN operands with -0 < +0
+inline double js_min2(double a, double b) {
+    if (a == 0.0 && b == 0.0) return std::signbit(a) ? a : b;
+    return a < b ? a : b;
+}
+inline double js_max2(double a, double b) {
+    if (a == 0.0 && b == 0.0) return std::signbit(a) ? b : a;
+    return a > b ? a : b;
+}
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+inline bool boxes_touch(const Box &a, const float *blo, const float *bhi) {  // boundingBox.ts:24-30
+    for (int k = 0; k < 3; ++k)
+        if (!(a.lo[k] <= bhi[k] && a.hi[k] >= blo[k])) return false;
+    return true;
+}
+
+double box_gap(const Box &a, const float *blo, const float *bhi) {  // boundingBox.ts:33-47
+    double g[3];
+    for (int k = 0; k < 3; ++k) {
+        g[k] = 0.0;
+        if (a.hi[k] < blo[k]) g[k] = double(blo[k]) - double(a.hi[k]);
+        else if (bhi[k] < a.lo[k]) g[k] = double(a.lo[k]) - double(bhi[k]);
+    }
+    return js_hypot3(g[0], g[1], g[2]);
+}
+
+// computeBounds (boundingBox.ts:158-169): left fold of merge; values are f32 already
+Box bounds_of(const HostScene &s, const int32_t *ids, int n) {
+    Box b;
+    if (n == 0) {
+        std::memset(&b, 0, sizeof b);
+        return b;
+    }
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = s.prim_lo[3 * ids[0] + k];
+        b.hi[k] = s.prim_hi[3 * ids[0] + k];
+    }
+    for (int i = 1; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = to_f32(js_min2(b.lo[k], s.prim_lo[3 * ids[i] + k]));
+            b.hi[k] = to_f32(js_max2(b.hi[k], s.prim_hi[3 * ids[i] + k]));
+        }
+    return b;
+}
+
+// ---- BVH (bvh.ts:29-92), emitted directly in right-first pre-order ---------------------
+
+struct BvhBuilder {
+    HostScene &s;
+    std::string &err;
+    bool ok = true;
+
+    int emit(std::vector<int32_t> &ids, const Box &box, int depth) {
+        const int me = static_cast<int>(s.bvh.size());
+        RmBvhNode node;
+        std::memcpy(node.lo, box.lo, sizeof node.lo);
+        std::memcpy(node.hi, box.hi, sizeof node.hi);
+        node.skip = 0;
+        node.leaf = -1;
+        s.bvh.push_back(node);
+        s.bvh_depth = std::max(s.bvh_depth, depth);
+        const int n = static_cast<int>(ids.size());
+
+        auto make_leaf = [&]() {
+            if (n > RM_BVH_LEAF_MAX) {
+                ok = false;
+                err = "BVH leaf with more than 255 primitives (depth limit 20 reached)";
+            }
+            const int first = static_cast<int>(s.bvh_prims.size());
+            s.bvh_prims.insert(s.bvh_prims.end(), ids.begin(), ids.end());
+            s.bvh[me].leaf = (first << 8) | (n & 0xFF);
+            s.bvh[me].skip = static_cast<int>(s.bvh.size());
+            s.bvh_leaves++;
+            return me;
+        };
+
+        if (depth >= 20 || n <= 2) return make_leaf();  // bvh.ts:52
+
+        // bvh.ts:58-63: longest axis of the f32 extent, strict > so ties keep x, then y
+        float ext[3];
+        for (int k = 0; k < 3; ++k) ext[k] = to_f32(double(box.hi[k]) - double(box.lo[k]));
+        int axis = 0;
+        if (ext[1] > ext[0]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+
+        // bvh.ts:66-70: stable sort by world position on that axis (centre, f32)
+        std::vector<int32_t> order(ids);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            const float ca = axis == 0 ? s.spheres[a].cx : axis == 1 ? s.spheres[a].cy : s.spheres[a].cz;
+            const float cb = axis == 0 ? s.spheres[b].cx : axis == 1 ? s.spheres[b].cy : s.spheres[b].cz;
+            return double(ca) - double(cb) < 0.0;
+        });
+        const int mid = n / 2;  // bvh.ts:73
+        std::vector<int32_t> left(order.begin(), order.begin() + mid);
+        std::vector<int32_t> right(order.begin() + mid, order.end());
+        if (left.empty() || right.empty()) return make_leaf();  // bvh.ts:78-81
+
+        const Box lb = bounds_of(s, left.data(), static_cast<int>(left.size()));
+        const Box rb = bounds_of(s, right.data(), static_cast<int>(right.size()));
+        emit(right, rb, depth + 1);  // popped first by bvh.ts:160-161
+        emit(left, lb, depth + 1);
+        s.bvh[me].skip = static_cast<int>(s.bvh.size());
+        return me;
+    }
+};
+
+// ---- Octree (octree.ts:36-191) ----------------------------------------------------------
+
+struct OctBuilder {
+    HostScene &s;
+
+    void fill(int me, const std::vector<int32_t> &ids, const Box &box, int depth) {
+        RmOctNode &node = s.oct[me];
+        std::memcpy(node.lo, box.lo, sizeof node.lo);
+        std::memcpy(node.hi, box.hi, sizeof node.hi);
+        node.first_child = -1;
+        node.prim_first = 0;
+        node.prim_count = 0;
+        node.is_empty = 1;
+        node.min_distance = 0.0;
+        const int n = static_cast<int>(ids.size());
+        if (depth >= 6 || n <= 4) {  // octree.ts:60
+            s.oct[me].prim_first = static_cast<int>(s.oct_prims.size());
+            s.oct[me].prim_count = n;
+            s.oct_prims.insert(s.oct_prims.end(), ids.begin(), ids.end());
+            return;
+        }
+        float c[3];  // boundingBox.ts:108-114, stored f32
+        for (int k = 0; k < 3; ++k) c[k] = to_f32((double(box.lo[k]) + double(box.hi[k])) / 2);
+        Box kid[8];
+        for (int i = 0; i < 8; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const bool upper = (i >> k) & 1;  // index = x + 2y + 4z (octree.ts:69-71)
+                kid[i].lo[k] = upper ? c[k] : box.lo[k];
+                kid[i].hi[k] = upper ? box.hi[k] : c[k];
+            }
+        std::vector<int32_t> share[8];
+        for (int32_t id : ids)  // octree.ts:93-103
+            for (int i = 0; i < 8; ++i)
+                if (boxes_touch(kid[i], &s.prim_lo[3 * id], &s.prim_hi[3 * id])) share[i].push_back(id);
+        const int first = static_cast<int>(s.oct.size());
+        s.oct.resize(s.oct.size() + 8);
+        s.oct[me].first_child = first;
+        for (int i = 0; i < 8; ++i) {
+            if (!share[i].empty()) fill(first + i, share[i], kid[i], depth + 1);
+            else fill(first + i, std::vector<int32_t>(), kid[i], 7);  // empty leaf, octree.ts:110-114
+        }
+    }
+
+    double nearest_prim_box(const RmOctNode &node) const {  // octree.ts:155-160
+        Box b;
+        std::memcpy(b.lo, node.lo, sizeof b.lo);
+        std::memcpy(b.hi, node.hi, sizeof b.hi);
+        double best = std::numeric_limits<double>::infinity();
+        const int n = static_cast<int>(s.spheres.size());
+        for (int i = 0; i < n; ++i) {
+            const double d = box_gap(b, &s.prim_lo[3 * i], &s.prim_hi[3 * i]);
+            if (d < best) best = d;
+        }
+        return best != std::numeric_limits<double>::infinity() ? js_max2(0.0, best) : 0.0;
+    }
+
+    bool mark(int me) {  // octree.ts:149-191
+        RmOctNode &node = s.oct[me];
+        if (node.first_child < 0) {
+            const bool has = node.prim_count > 0;
+            node.is_empty = has ? 0 : 1;
+            node.min_distance = has ? 0.0 : nearest_prim_box(node);
+            s.oct_leaves++;
+            if (!has) s.oct_empty++;
+            s.oct_max_leaf = std::max(s.oct_max_leaf, node.prim_count);
+            return has;
+        }
+        bool any = false;
+        const int first = node.first_child;
+        for (int i = 0; i < 8; ++i)
+            if (mark(first + i)) any = true;
+        s.oct[me].is_empty = any ? 0 : 1;
+        s.oct[me].min_distance = any ? 0.0 : nearest_prim_box(s.oct[me]);
+        return any;
+    }
+};
+
+}  // namespace
+
+double js_hypot3(double x, double y, double z) {
+    double v[3] = {std::fabs(x), std::fabs(y), std::fabs(z)};
+    double big = 0.0;
+    bool nan = false;
+    for (double a : v) {
+        if (a != a) nan = true;
+        else if (a > big) big = a;
+    }
+    if (big == std::numeric_limits<double>::infinity()) return big;
+    if (nan) return std::numeric_limits<double>::quiet_NaN();
+    if (big == 0.0) return 0.0;
+    double sum = 0.0, comp = 0.0;
+    for (double a : v) {
+        const double q = a / big;
+        const double term = q * q - comp;
+        const double next = sum + term;
+        comp = (next - sum) - term;
+        sum = next;
+    }
+    return std::sqrt(sum) * big;
+}
+
+bool preset_spheres(int index, std::vector<float> &centers, std::vector<double> &radii) {
+    centers.clear();
+    radii.clear();
+    index = std::max(0, std::min(index, kPresetCount - 1));  // scene.ts:39
+    auto add = [&](double x, double y, double z, double r) {
+        // createSphere -> getTransform: translation stored f32 (sceneManager.ts:31)
+        centers.push_back(to_f32(x));
+        centers.push_back(to_f32(y));
+        centers.push_back(to_f32(z));
+        radii.push_back(r);
+    };
+    switch (index) {
+        case 0:  // "Sphere"
+            add(0, 0, 0, 1.5);
+            return true;
+        case 1:  // "Random Spheres"
+            add(0.8, -0.3, 0.2, 0.4);
+            add(-0.5, 0.9, -0.1, 0.5);
+            add(0.2, 0.1, 0.8, 0.3);
+            add(-0.9, -0.4, -0.6, 0.6);
+            add(0.4, -0.8, 0.5, 0.35);
+            add(-0.2, 0.6, -0.9, 0.4);
+            add(0.7, 0.3, -0.4, 0.25);
+            return true;
+        case 2:  // "Grid of Spheres"
+            for (int y = -1; y <= 1; ++y)
+                for (int x = -1; x <= 1; ++x) add(x, y, 0, 0.3);
+            return true;
+        case 3: {  // "Dense Sphere Grid"
+            const int grid = 5;
+            const double spacing = 0.6;
+            const double offset = (grid - 1) * spacing / 2;
+            for (int x = 0; x < grid; ++x)
+                for (int y = 0; y < grid; ++y)
+                    for (int z = 0; z < grid; ++z)
+                        add(x * spacing - offset, y * spacing - offset, z * spacing - offset, 0.15);
+            return true;
+        }
+        case 4:  // "Atom"
+            add(0, 0, 0, 0.5);
+            add(1.2, 0, 0, 0.3);
+            add(-1.2, 0, 0, 0.3);
+            add(0, 1.2, 0, 0.3);
+            add(0, -1.2, 0, 0.3);
+            add(0, 0, 1.2, 0.3);
+            add(0, 0, -1.2, 0.3);
+            return true;
+        default:
+            return false;  // box / torus / mandelbulb / operator presets: out of scope
+    }
+}
+
+bool build_scene(HostScene &s, const float *centers, const double *radii, int n, int accel,
+                 std::string &err) {
+    if (n < 0 || (n > 0 && (!centers || !radii))) {
+        err = "bad sphere list";
+        return false;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!std::isfinite(centers[3 * i]) || !std::isfinite(centers[3 * i + 1]) ||
+            !std::isfinite(centers[3 * i + 2]) || !std::isfinite(radii[i])) {
+            err = "non-finite sphere centre or radius";
+            return false;
+        }
+    }
+    s = HostScene();
+    s.accel = (accel == 1 || accel == 2) ? accel : 0;
+    s.spheres.resize(n);
+    s.radii.assign(radii, radii + n);
+    s.prim_lo.resize(3 * size_t(n));
+    s.prim_hi.resize(3 * size_t(n));
+    for (int i = 0; i < n; ++i) {
+        s.spheres[i] = RmSphere{centers[3 * i], centers[3 * i + 1], centers[3 * i + 2], to_f32(radii[i])};
+        // BoundingBox.fromPrimitive (boundingBox.ts:133-154): local->world is identity
+        // + translation, so each column has Math.hypot(1,0,0) = 1 and maxScale = 1.
+        const double scale = js_max2(js_max2(js_hypot3(1, 0, 0), js_hypot3(0, 1, 0)), js_hypot3(0, 0, 1));
+        const double pad = radii[i] * scale * 1.5;
+        for (int k = 0; k < 3; ++k) {
+            s.prim_lo[3 * i + k] = to_f32(double(centers[3 * i + k]) - pad);
+            s.prim_hi[3 * i + k] = to_f32(double(centers[3 * i + k]) + pad);
+        }
+    }
+    std::vector<int32_t> all(n);
+    std::iota(all.begin(), all.end(), 0);
+    if (s.accel == 2) {
+        const Box root = bounds_of(s, all.data(), n);  // bvh.ts:38-41 (ctor bounds arg ignored)
+        BvhBuilder b{s, err};
+        b.emit(all, root, 0);
+        if (!b.ok) return false;
+        std::memcpy(s.root_min, root.lo, sizeof root.lo);
+        std::memcpy(s.root_max, root.hi, sizeof root.hi);
+    } else if (s.accel == 1) {
+        Box root;  // scene.ts:81-85
+        for (int k = 0; k < 3; ++k) {
+            root.lo[k] = -10.0f;
+            root.hi[k] = 10.0f;
+        }
+        s.oct.resize(1);
+        OctBuilder b{s};
+        b.fill(0, all, root, 0);
+        b.mark(0);
+        std::memcpy(s.root_min, root.lo, sizeof root.lo);
+        std::memcpy(s.root_max, root.hi, sizeof root.hi);
+    }
+    return true;
+}
+
+void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]) {
+    const double half_pi = 3.141592653589793 / 2;
+    const double p = js_min2(js_max2(pitch, -half_pi), half_pi);  // camera.ts:59
+    const Mat4 orbit = rotate_x(rotate_y(Mat4::identity(), yaw), p);  // camera.ts:83-84
+    const float back[3] = {0.0f, 0.0f, 3.0f};                       // camera.ts:13,86
+    const Mat4 cam = translate(orbit, back);
+    const int src[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};  // mat3.fromMat4
+    for (int i = 0; i < 9; ++i) rot9[i] = cam.m[src[i]];
+    origin3[0] = cam.m[12];
+    origin3[1] = cam.m[13];
+    origin3[2] = cam.m[14];
+}
+
+void phong_light_dir(float out[3]) {
+    const float v[3] = {1.0f, -1.0f, 1.5f};
+    double len = double(v[0]) * v[0] + double(v[1]) * v[1] + double(v[2]) * v[2];
+    if (len > 0) len = 1 / std::sqrt(len);
+    for (int k = 0; k < 3; ++k) out[k] = to_f32(double(v[k]) * len);
+}
+
+}  // namespace rmh

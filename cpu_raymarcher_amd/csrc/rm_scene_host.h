@@ -1,0 +1,46 @@
+// rm_scene_host.h -- host-side scene construction for the MI355X render path: sphere
+// presets, camera matrices, BVH / Octree build and flattening into the device layout of
+// rm_types.h.  Runs once per scene change (the reference rebuilds per tile per frame,
+// raymarchWorker.ts:37-38).  Pure C++, no HIP.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "rm_types.h"
+
+namespace rmh {
+
+constexpr int kPresetCount = 19;  // sceneManager.ts:102-357
+
+struct HostScene {
+    int accel = 0;
+    int preset = 0;
+    std::vector<RmSphere> spheres;
+    std::vector<double> radii;
+    std::vector<float> prim_lo, prim_hi;  // padded AABBs, 3 floats per primitive
+    std::vector<RmBvhNode> bvh;
+    std::vector<int32_t> bvh_prims;
+    int bvh_leaves = 0, bvh_depth = 0;
+    std::vector<RmOctNode> oct;
+    std::vector<int32_t> oct_prims;
+    int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+};
+
+// V8 Math.hypot for three arguments (used by boundingBox.ts:46,142-144)
+double js_hypot3(double x, double y, double z);
+
+// sceneManager.ts:102-170: sphere-only presets 0..4; false for the others
+bool preset_spheres(int index, std::vector<float> &centers, std::vector<double> &radii);
+
+// Builds spheres + acceleration structure.  Returns false and sets err on bad input.
+bool build_scene(HostScene &s, const float *centers, const double *radii, int n, int accel,
+                 std::string &err);
+
+// camera.ts:58-69,81-88 + raymarcher.ts:62-67
+void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]);
+
+// phongModel.ts:15-16
+void phong_light_dir(float out[3]);
+
+}  // namespace rmh

@@ -1,0 +1,76 @@
+// rm_types.h -- device-resident data layout shared by the host builder and the HIP kernels.
+//
+// Layout in HBM (all read-only during a render, replicated per GPU):
+//   spheres   : RmSphere[n]     16 B  centre f32x3 + f32(radius) (radius copy feeds the
+//                                      conservative f32 candidate filter only)
+//   radii     : double[n]        8 B  Sphere.radius stays a JS double (sphere.ts:5-9)
+//   bvh       : RmBvhNode[nodes] 32 B  right-first pre-order with skip links (see below)
+//   bvh_prims : int32[...]             leaf primitive ids, leaf order
+//   oct       : RmOctNode[nodes] 48 B  children of a node are 8 consecutive entries
+//   oct_prims : int32[...]             leaf primitive ids
+// Dense Sphere Grid: 125 spheres (2 KB + 1 KB), 127 BVH nodes (4 KB).  10k synthetic:
+// 160 KB + 80 KB spheres, 2441 octree nodes (117 KB) + ~1.2 MB of leaf ids.
+#pragma once
+#include <stdint.h>
+
+// One BVH node (bvh.ts:6-22), flattened.  Nodes are stored in the order in which
+// BVH.findRayIntersections (bvh.ts:136-173) pops them: it pushes left then right, so the
+// RIGHT child is visited first.  In that order the first child of node i is i + 1 and
+// `skip` is the next node to visit once the subtree of i is finished or pruned; a
+// traversal is `i = descend ? i + 1 : skip` with no stack, and the node index doubles as
+// the traversal sequence number that breaks ties in the stable sort of bvh.ts:176.
+struct RmBvhNode {
+    float lo[3];
+    int32_t skip;  // == node count for "end of traversal"
+    float hi[3];
+    int32_t leaf;  // -1: internal node; else (first << 8) | count into bvh_prims
+};
+
+// One octree node (octree.ts:6-26), flattened.
+struct RmOctNode {
+    float lo[3];
+    int32_t first_child;  // -1: leaf; else index of child 0 (children are consecutive,
+                          // index = x + 2y + 4z, octree.ts:69-88)
+    float hi[3];
+    int32_t prim_first;   // into oct_prims
+    double min_distance;  // octree.ts:149-191 (0 unless isEmpty)
+    int32_t prim_count;
+    int32_t is_empty;
+};
+
+struct RmSphere {
+    float cx, cy, cz;
+    float rf;  // (float)radius, used only by the conservative candidate filter
+};
+
+#define RM_BVH_LEAF_MAX 255
+#define RM_MAX_STEPS 100
+#define RM_MAX_DIST 10.0
+#define RM_EPSILON 0.001
+
+// Kernel parameters (passed by value; < 256 B).
+struct RmRenderParams {
+    int32_t width, height, y_start, y_end;
+    float rot[9];     // mat3.fromMat4(camera rotation), column-major
+    float origin[3];  // camera position
+    float light[3];   // normalize(f32(1,-1,1.5)) as phongModel.ts:15-16 computes it
+    int32_t n_prims;
+    int32_t accel;    // rm_accel
+    int32_t shader;   // rm_shader, used when rgba != nullptr
+    int32_t bvh_nodes;
+    int32_t oct_nodes;
+    int32_t tile_w;   // pixels per wave row (64, 32, 16 or 8); wave tile = tile_w x (64 / tile_w)
+    int32_t nodes_in_lds;
+    int32_t filter;   // 1: conservative f32 candidate filter for N-primitive loops
+    const RmSphere *spheres;
+    const double *radii;
+    const RmBvhNode *bvh;
+    const int32_t *bvh_prims;
+    const RmOctNode *oct;
+    const int32_t *oct_prims;
+    uint8_t *depth;
+    uint8_t *normal;
+    uint16_t *sdf;
+    uint16_t *iters;
+    uint8_t *rgba;
+};

@@ -1,0 +1,207 @@
+/*
+ * rm_raymarch.h -- C ABI of the MI355X-native sphere-tracing render path.
+ *
+ * Drop-in boundary for ONE path of vxlerian/cpu-raymarcher: the per-pixel render path
+ *   worker tile dispatch -> Raymarcher.runRaymarcher -> SphereTracer.rayMarch
+ *   -> BVH / Octree callbacks -> Scene.getDistance -> Sphere.sdf, then ShadingModel.shade
+ * (reference files cited per entry point, paths relative to the reference's src/).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns an
+ * rm_status (0 = ok, negative = error) unless stated; nothing throws or aborts across
+ * the boundary (the reference has no error path on this route: bad inputs are clamped
+ * or defaulted exactly as the reference does, see each entry).
+ *
+ * Buffers follow the reference's typed arrays (raymarchWorker.ts:42-46):
+ *   depth  : uint8  [W*h]      Uint8ClampedArray
+ *   normal : uint8  [W*h*3]    Uint8ClampedArray, RGB interleaved
+ *   sdf    : uint16 [W*h]      Uint16Array  (SDF evaluations per pixel, wraps mod 65536)
+ *   iters  : uint16 [W*h]      Uint16Array  (march iterations per pixel)
+ *   rgba   : uint8  [W*h*4]    Uint8ClampedArray (ImageData)
+ * all tile-local, row-major, h = max(0, yEnd - yStart).  The caller owns every buffer;
+ * the library never frees or retains one (the reference transfers ownership back to the
+ * main thread, raymarchWorker.ts:86-91).
+ *
+ * Threading: an rm_ctx is bound to one GPU and is not thread-safe; use one ctx per host
+ * thread / GPU (the reference keeps one job in flight per worker, main.ts:447-490).
+ */
+#ifndef RM_RAYMARCH_H
+#define RM_RAYMARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_API __attribute__((visibility("default")))
+
+typedef struct rm_ctx rm_ctx;
+
+typedef enum rm_status {
+    RM_OK = 0,
+    RM_E_INVALID = -1,     /* null pointer, negative size, non-finite camera ...            */
+    RM_E_UNSUPPORTED = -2, /* preset with non-sphere primitives; marcher other than sphere  */
+                           /* tracer (host may fall back to its own CPU path)               */
+    RM_E_NO_DEVICE = -3,   /* ctx was created host-only, or no HIP device                   */
+    RM_E_HIP = -4,         /* a HIP runtime call failed; rm_last_error has the text         */
+    RM_E_NO_SCENE = -5,    /* render requested before any scene was set                     */
+    RM_E_NOMEM = -6
+} rm_status;
+
+/* Scene.accelerationStructure strings "None" | "Octree" | "BVH" (scene.ts:21,32-36) */
+typedef enum rm_accel { RM_ACCEL_NONE = 0, RM_ACCEL_OCTREE = 1, RM_ACCEL_BVH = 2 } rm_accel;
+
+/* Job.algorithm strings (raymarchWorker.ts:50-68) */
+typedef enum rm_algorithm {
+    RM_ALG_SPHERE_TRACER = 0, /* 'sphere-tracer' and every unknown string (default branch) */
+    RM_ALG_FIXED_STEP = 1,
+    RM_ALG_ADAPTIVE_STEP = 2,
+    RM_ALG_ADAPTIVE_STEP_V2 = 3,
+    RM_ALG_ADAPTIVE_STEP_V3 = 4
+} rm_algorithm;
+
+/* shading model strings (main.ts:33-45) */
+typedef enum rm_shader {
+    RM_SHADE_NORMAL = 0, /* 'normal' and every unknown string */
+    RM_SHADE_PHONG = 1,
+    RM_SHADE_SDF_HEATMAP = 2,
+    RM_SHADE_ITERATION_HEATMAP = 3
+} rm_shader;
+
+/* scene_preset_index value that selects the scene last given to rm_scene_from_spheres */
+#define RM_SCENE_UPLOADED INT32_MIN
+
+/* Replaces the worker message `Job` (raymarchWorker.ts:10-22).  The reference worker
+ * rebuilds the scene from (scenePresetIndex, accelerationStructure) for every job
+ * (raymarchWorker.ts:37-38); here the ctx caches the built, device-resident scene and
+ * rebuilds only when those two fields change. */
+typedef struct rm_job {
+    int32_t width;                  /* Job.width  : full-frame width                     */
+    int32_t height;                 /* Job.height : full-frame height                    */
+    double  time;                   /* Job.time   : unused by sphere primitives          */
+    int32_t y_start;                /* Job.yStart                                        */
+    int32_t y_end;                  /* Job.yEnd   (rows [y_start, y_end))                */
+    double  camera_pitch;           /* Job.camera.pitch (clamped to +-pi/2, camera.ts:59) */
+    double  camera_yaw;             /* Job.camera.yaw                                    */
+    int32_t algorithm;              /* rm_algorithm                                      */
+    int32_t scene_preset_index;     /* clamped to [0, 18] (scene.ts:39) or RM_SCENE_UPLOADED */
+    int32_t acceleration_structure; /* rm_accel                                          */
+    int32_t reserved;
+    double  overshoot_factor;       /* Job.overshootFactor (unused by sphere tracer)     */
+    double  step_size;              /* Job.stepSize        (unused by sphere tracer)     */
+} rm_job;
+
+/* what rm_scene_get_info reports about the built acceleration structure */
+typedef struct rm_scene_info {
+    int32_t n_prims;
+    int32_t accel;           /* rm_accel */
+    int32_t preset_index;    /* or RM_SCENE_UPLOADED */
+    int32_t bvh_nodes, bvh_leaves, bvh_depth;
+    int32_t oct_nodes, oct_leaves, oct_empty_leaves, oct_max_leaf_prims;
+    float   root_min[3], root_max[3];
+    int32_t nodes_in_lds;    /* 1 when the flattened node table is staged in LDS */
+    int32_t reserved;
+} rm_scene_info;
+
+/* diagnostics of main.ts:528-548 */
+typedef struct rm_diagnostics {
+    uint64_t total_sdf_calls;
+    uint64_t total_iterations;
+    uint32_t max_sdf_calls;
+    uint32_t min_sdf_calls;  /* Number.MAX_SAFE_INTEGER in the reference when n == 0; UINT32_MAX here */
+    uint64_t total_pixels;
+} rm_diagnostics;
+
+/* ---- context ------------------------------------------------------------------- */
+
+/* device >= 0: bind to that HIP device.  device == -1: host-only ctx (scene building and
+ * camera only; every render entry returns RM_E_NO_DEVICE).  There is no CPU fallback. */
+RM_API int rm_create(int device, rm_ctx **out);
+RM_API void rm_destroy(rm_ctx *ctx);
+RM_API const char *rm_last_error(const rm_ctx *ctx); /* never NULL */
+RM_API const char *rm_version(void);
+
+/* string -> enum with the reference's defaulting rules (never fail) */
+RM_API int rm_algorithm_from_string(const char *s); /* raymarchWorker.ts:50-68 */
+RM_API int rm_accel_from_string(const char *s);     /* scene.ts:32-36          */
+RM_API int rm_shader_from_string(const char *s);    /* main.ts:33-45           */
+RM_API int rm_preset_count(void);                   /* sceneManager.ts:363-365 */
+
+/* ---- scene --------------------------------------------------------------------- */
+
+/* Replaces `new Scene(accel); scene.loadPreset(index)` (scene.ts:24-59,
+ * raymarchWorker.ts:37-38): builds the primitive list, the BVH (bvh.ts:29-92) or Octree
+ * (octree.ts:36-191), flattens it and uploads it.  Sphere-only presets 0..4 are native;
+ * the others return RM_E_UNSUPPORTED. */
+RM_API int rm_scene_from_preset(rm_ctx *ctx, int32_t preset_index, int32_t accel);
+
+/* Build-defined scene entry: n spheres as SceneManager.createSphere(x, y, z, r) without
+ * rotation would make them (sceneManager.ts:21-41): centre f32, radius a double
+ * (sphere.ts:5-9).  Selected in jobs by scene_preset_index = RM_SCENE_UPLOADED. */
+RM_API int rm_scene_from_spheres(rm_ctx *ctx, const float *centers_xyz, const double *radii,
+                                 int32_t n, int32_t accel);
+
+RM_API int rm_scene_get_info(const rm_ctx *ctx, rm_scene_info *out);
+
+/* Camera.setAngles + getRotationMatrix/getPosition (camera.ts:38-44,58-69,81-88):
+ * writes mat3.fromMat4 of the rotation (9 floats, column-major) and the origin. */
+RM_API int rm_camera_from_angles(double pitch, double yaw, float *rot9, float *origin3);
+
+/* Scene.getDistance(position, counter) (scene.ts:144-190) for a batch of points, on the
+ * device: dist[i] and count[i] (primitives evaluated) for points xyz f32[3n] (host). */
+RM_API int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *dist,
+                             uint32_t *count);
+
+/* ---- render -------------------------------------------------------------------- */
+
+/* Replaces the worker's onmessage (raymarchWorker.ts:33-92) = Raymarcher.runRaymarcher
+ * (raymarcher.ts:46-109) for one row tile, host buffers (synchronous).  Counters are
+ * (re)initialised per pixel (raymarcher.ts:79-80); buffers need no pre-clear. */
+RM_API int rm_render_tile(rm_ctx *ctx, const rm_job *job, uint8_t *depth, uint8_t *normal,
+                          uint16_t *sdf, uint16_t *iters);
+
+/* Same with device pointers (hipMalloc / torch CUDA tensors), asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream).  rgba may be NULL; when not,
+ * ShadingModel.shade (shading_models/, all four) is fused behind the march.  depth, normal, sdf, iters may
+ * each be NULL when the caller does not want that G-buffer (rgba then still sees them). */
+RM_API int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader, void *d_depth,
+                                 void *d_normal, void *d_sdf, void *d_iters, void *d_rgba,
+                                 void *stream);
+
+/* Replaces ShadingModel.shade(shaded, depth, normal, sdfEval, iters, width, height)
+ * (shadingModel.ts:8-17 and the four models), host buffers. */
+RM_API int rm_shade(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height,
+                    const uint8_t *depth, const uint8_t *normal, const uint16_t *sdf,
+                    const uint16_t *iters, uint8_t *rgba);
+RM_API int rm_shade_device(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height,
+                           const void *d_depth, const void *d_normal, const void *d_sdf,
+                           const void *d_iters, void *d_rgba, void *stream);
+
+/* Replaces the diagnostics pass of main.ts:528-548. */
+RM_API int rm_reduce_counters(rm_ctx *ctx, const uint16_t *sdf, const uint16_t *iters, int64_t n,
+                              rm_diagnostics *out);
+/* device buffers; result written to host `out` after a stream sync */
+RM_API int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n,
+                                     rm_diagnostics *out, void *stream);
+
+/* ---- tile partition (main.ts:444-450) ------------------------------------------- */
+
+/* rows of worker i of n: [min(i*r, H), min((i+1)*r, H)) with r = ceil(H / n) */
+RM_API int rm_partition_rows(int32_t height, int32_t n_workers, int32_t i, int32_t *y_start,
+                             int32_t *y_end);
+
+/* ---- device numerics self-test (parity aid, not part of the reference surface) ---- */
+
+/* V8 Math.hypot of n float triples evaluated by the device code path used in Sphere.sdf */
+RM_API int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out);
+
+/* kernel-variant knobs for measurement (tile shape, LDS staging ...); unknown keys are
+ * RM_E_INVALID.  Never changes results. */
+RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
+RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RM_RAYMARCH_H */

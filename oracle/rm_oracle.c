@@ -1115,3 +1115,26 @@ void ro_scene_spheres(const ro_scene *s, float *centers, double *radii) {
         radii[i] = s->prims[i].radius;
     }
 }
+
+/* histogram of per-ray BVH interval-list lengths (design aid for the GPU kernel's list
+ * capacity; not part of the reference's path).  hist has nbins entries; last bin = overflow */
+void ro_debug_interval_hist(const ro_scene *s, int width, int height, long *hist, int nbins) {
+    if (!s->bvh) return;
+    const float *ct = s->cameraTransform;
+    float rotMat3[9] = {ct[0], ct[1], ct[2], ct[4], ct[5], ct[6], ct[8], ct[9], ct[10]};
+    float rayOrigin[3] = {ct[12], ct[13], ct[14]};
+    Interval *iv = (Interval *)malloc((size_t)s->bvh_leaves * sizeof(Interval));
+    const BVHNode **stack = (const BVHNode **)malloc((size_t)s->bvh_nodes * sizeof(BVHNode *));
+    for (int y = 0; y < height; y++) {
+        double v = ((double)y / (double)height - 0.5) * 2.0;
+        for (int x = 0; x < width; x++) {
+            double u = ((double)x / (double)width - 0.5) * 2.0;
+            float rayDir[3] = {f32(u), f32(v), -1.0f};
+            vec3_transformMat3(rayDir, rayDir, rotMat3);
+            vec3_normalize(rayDir, rayDir);
+            int n = bvh_find_intervals(s, rayOrigin, rayDir, 0, MAX_DIST, iv, stack);
+            hist[n < nbins - 1 ? n : nbins - 1]++;
+        }
+    }
+    free(iv); free((void *)stack);
+}

@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X sphere-tracing render path.
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+one rank per GPU, RCCL through torch.distributed.)
+
+A step = one frame of BASELINE.json's metric workload (C3: Dense Sphere Grid, 125 spheres,
+3840x2160, sphere tracing + BVH, iteration-heatmap shader): render + fused shade into
+{depth, normal, sdfEval, iters, RGBA} resident in HBM, then the diagnostics reduction of
+main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the ranks
+(interleaved 16-row stripes) and {RGBA, sdfEval, iters} are gathered to rank 0 and
+reassembled -- total work fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- HBM: 12 B/pixel of mandatory output / render-kernel time (HIP events)
+  cpu_baseline -- the oracle (C restatement, kind "port") on the host cores, rank 0, N = 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_PIXEL = 12  # depth 1 + normal 3 + sdfEval 2 + iters 2 + RGBA 4, ~0 read
+
+WORKLOADS = {
+    "C2": dict(name="C2: Grid of Spheres (9), 1920x1080, sphere-tracing + BVH, Phong shader",
+               preset=2, accel="BVH", width=1920, height=1080, shader="phong"),
+    "C3": dict(name="C3: Dense Sphere Grid (125 spheres), 3840x2160, sphere-tracing + BVH, iteration-heatmap shader",
+               preset=3, accel="BVH", width=3840, height=2160, shader="iteration-heatmap"),
+    "C5": dict(name="C5: synthetic 10000 random spheres (splitmix64 0x5EED5EED), 3840x2160, sphere-tracing + Octree, "
+                    "iteration-heatmap shader",
+               synthetic=10000, accel="Octree", width=3840, height=2160, shader="iteration-heatmap"),
+}
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """Oracle (C restatement of the reference's path) on this host's cores.  Bounded sample:
+    every `stride`-th row of the same frame, rows spread over a thread pool (ctypes drops
+    the GIL), scaled to frames/s; stride is chosen from a quick probe so the sample costs
+    about `budget_s` of CPU work."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    W, H = wl["width"], wl["height"]
+    spheres = O.synthetic_spheres(wl["synthetic"]) if "synthetic" in wl else None
+    sc = O.OracleScene(preset=wl.get("preset"), accel=wl["accel"], spheres=spheres)
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 64))
+    t0 = time.time()
+    probe_rows = list(range(H // 64, H, H // 8))[:8]
+    for y in probe_rows:
+        sc.render(W, H, y, y + 1)
+    per_row = (time.time() - t0) / len(probe_rows)
+    stride = max(1, int(per_row * H / budget_s + 0.999))
+    rows = list(range(0, H, stride))
+
+    def work(y):
+        d, n, s, i = sc.render(W, H, y, y + 1)
+        O.shade(wl["shader"], d, n, s, i, W, 1)
+        return int(s.astype("int64").sum())
+
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, rows))
+    dt = time.time() - t0
+    fps = 1.0 / (dt * H / len(rows))
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "every %d-th row of the %dx%d frame (%d rows, %.1f s wall on %d threads), oracle/rm_oracle.c "
+                      "render + shade, scaled by H/rows" % (stride, W, H, len(rows), dt, cores),
+            "sample_avg_sdf_calls_per_pixel": total / (len(rows) * W)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--partition", default="interleaved", choices=["interleaved", "contiguous"])
+    ap.add_argument("--stripe", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (rm_set_option)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cpu_raymarcher_amd as R
+    from cpu_raymarcher_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    W, H = wl["width"], wl["height"]
+    ctx = R.Context(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    scene = R.Scene(wl["accel"], ctx=ctx)
+    if "synthetic" in wl:
+        from oracle.oracle import synthetic_spheres  # scene generator only (SURVEY 8d C5 definition)
+        sp = synthetic_spheres(wl["synthetic"])
+        scene.loadSpheres(sp[:, :3], sp[:, 3])
+    else:
+        scene.loadPreset(wl["preset"])
+    tracer = R.SphereTracer()
+    u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)  # noqa: E731
+    acc = torch.zeros(4, dtype=torch.int64, device=dev)
+    ev_pairs = []
+
+    if world == 1:
+        depth, normal, rgba = u8(W * H), u8(3 * W * H), u8(4 * W * H)
+        sdf = torch.zeros(W * H, dtype=torch.int16, device=dev)
+        iters = torch.zeros(W * H, dtype=torch.int16, device=dev)
+
+        def step(timed):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            tracer.runRaymarcher(scene, depth, normal, sdf, iters, W, H, 0.0, shadedBuffer=rgba, shader=wl["shader"])
+            if timed:
+                e1.record()
+                ev_pairs.append((e0, e1))
+            ctx.reduce_counters_enqueue(sdf, iters, acc)
+
+        def finish():
+            pass
+    else:
+        layout = D.FrameLayout(W, H, world, ("rgba", "sdf", "iters"), args.partition, args.stripe)
+        render_rows = D.gpu_render_rows(ctx, scene, W, H, wl["shader"], layout)
+        timed_flag = [False]
+
+        def timed_render_rows(a, b, local, packed):
+            if timed_flag[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                render_rows(a, b, local, packed)
+                e1.record()
+                ev_pairs.append((e0, e1))
+            else:
+                render_rows(a, b, local, packed)
+
+        shr = D.ShardedFrameRenderer(layout, rank, world, timed_render_rows, u8, dist)
+        # rank 0 reassembly: one indexed row-gather per section
+        if rank == 0:
+            frame = {s: u8(D.SECTION_BYTES[s] * W * H) for s in layout.sections}
+            rank_of_row = torch.empty(H, dtype=torch.int64)
+            local_of_row = torch.empty(H, dtype=torch.int64)
+            for r in range(world):
+                loc = 0
+                for (a, b) in layout.rows(r):
+                    rank_of_row[a:b] = r
+                    local_of_row[a:b] = torch.arange(loc, loc + b - a)
+                    loc += b - a
+            rank_of_row, local_of_row = rank_of_row.to(dev), local_of_row.to(dev)
+            recv2d = [torch.zeros(world, layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(shr.nbuf)]
+            shr.recv = [list(t.unbind(0)) for t in recv2d]
+
+        def assemble(slot):
+            for s in layout.sections:
+                bpp = D.SECTION_BYTES[s]
+                off = layout.offsets[s]
+                src = recv2d[slot][:, off:off + layout.cap * W * bpp].unflatten(1, (layout.cap, W * bpp))
+                frame[s].view(H, W * bpp).copy_(src[rank_of_row, local_of_row])
+            ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), acc)
+
+        pending = []
+
+        def step(timed):
+            timed_flag[0] = timed
+            slot = shr.submit()
+            pending.append(slot)
+            if len(pending) > 1:  # frame n-1 is assembled while frame n renders / gathers
+                s0 = pending.pop(0)
+                shr.finish(s0)
+                if rank == 0:
+                    assemble(s0)
+
+        def finish():
+            while pending:
+                s0 = pending.pop(0)
+                shr.finish(s0)
+                if rank == 0:
+                    assemble(s0)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    finish()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    finish()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the render kernel.  Average launch duration from the HIP events recorded
+    # on the launch stream; per launch this rank rendered rows_launched / launches pixels-rows.
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    if world == 1:
+        px_per_launch = W * H
+    else:
+        rows_mine = layout.rows(rank)
+        px_per_launch = W * sum(b - a for a, b in rows_mine) / max(1, len(rows_mine))
+    achieved = ALG_BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    if rank == 0:
+        d = ctx.decode_acc(acc)
+        fps = args.steps / elapsed
+        out = {
+            "metric": "frames/sec, 3840x2160 Dense-Grid sphere-trace (+ avg SDF-calls/pixel)" if args.workload == "C3"
+                      else "frames/sec, " + wl["name"],
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["name"], "width": W, "height": H, "acceleration_structure": wl["accel"],
+                       "shader": wl["shader"], "camera": {"pitch": 0.0, "yaw": 0.0},
+                       "parallelism": "1 GPU" if world == 1 else
+                       "row-tile shard x%d (%s, stripe %d) + RCCL gather of RGBA+sdfEval+iters to rank 0"
+                       % (world, args.partition, args.stripe)},
+            "avg_sdf_calls_per_pixel": d["total_sdf"] / (W * H), "avg_iterations_per_pixel": d["total_iters"] / (W * H),
+            "max_sdf_calls": d["max_sdf"], "min_sdf_calls": d["min_sdf"],
+            "sphere_evals_per_s": d["total_sdf"] * fps,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "render_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_PIXEL * px_per_launch,
+                         "note": "FP64-VALU/divergence bound, not HBM bound: 12 B/pixel out, ~1e3 FP64 ops/pixel "
+                                 "(DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

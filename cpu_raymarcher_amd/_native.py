@@ -78,6 +78,7 @@ SIGNATURES = {
     "rm_shade_device": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rm_reduce_counters": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics)]),
     "rm_reduce_counters_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics), _VP]),
+    "rm_reduce_counters_enqueue": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "rm_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rm_selftest_hypot": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),

@@ -128,6 +128,18 @@ class Context:
                 "max_sdf": int(out.max_sdf_calls), "min_sdf": int(out.min_sdf_calls),
                 "total_pixels": int(out.total_pixels)}
 
+    def reduce_counters_enqueue(self, sdf, iters, acc):
+        """Async diagnostics for a frame loop: `acc` is a CUDA int64[4] tensor that receives
+        (total_sdf, total_iters, max_sdf | min_sdf << 32, pad); read it with decode_acc()."""
+        N.check(self._h, N.lib().rm_reduce_counters_enqueue(self._h, _ptr(sdf), _ptr(iters), int(sdf.numel()),
+                                                            _ptr(acc), _current_stream_ptr()))
+
+    @staticmethod
+    def decode_acc(acc):
+        v = [int(x) for x in acc.cpu().tolist()]
+        return {"total_sdf": v[0], "total_iters": v[1], "max_sdf": v[2] & 0xFFFFFFFF,
+                "min_sdf": (v[2] >> 32) & 0xFFFFFFFF}
+
     def selftest_hypot(self, xyz):
         a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         out = np.zeros(len(a), np.float64)

@@ -399,21 +399,26 @@ int rm_shade(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height, const u
     return RM_OK;
 }
 
-int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n, rm_diagnostics *out,
-                              void *stream) {
-    if (!ctx || !out) return RM_E_INVALID;
+int rm_reduce_counters_enqueue(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n, void *d_acc,
+                               void *stream) {
+    if (!ctx || !d_acc) return RM_E_INVALID;
     if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
     if (n < 0 || (n > 0 && (!d_sdf || !d_iters))) return fail(ctx, RM_E_INVALID, "bad buffers");
     RM_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    RmDiagDevice init;
-    init.total_sdf = 0;
-    init.total_iters = 0;
-    init.max_sdf = 0;
-    init.min_sdf = 0xFFFFFFFFu;
-    RM_HIP(ctx, hipMemcpyAsync(ctx->d_diag, &init, sizeof init, hipMemcpyHostToDevice, st));
+    RM_HIP(ctx, rm_launch_reduce_init(static_cast<RmDiagDevice *>(d_acc), st));
     RM_HIP(ctx, rm_launch_reduce(static_cast<const uint16_t *>(d_sdf), static_cast<const uint16_t *>(d_iters), n,
-                                 ctx->d_diag, st));
+                                 static_cast<RmDiagDevice *>(d_acc), st));
+    return RM_OK;
+}
+
+int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n, rm_diagnostics *out,
+                              void *stream) {
+    if (!ctx || !out) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc0 = rm_reduce_counters_enqueue(ctx, d_sdf, d_iters, n, ctx->d_diag, stream);
+    if (rc0) return rc0;
     RmDiagDevice res;
     RM_HIP(ctx, hipMemcpyAsync(&res, ctx->d_diag, sizeof res, hipMemcpyDeviceToHost, st));
     RM_HIP(ctx, hipStreamSynchronize(st));

@@ -5,11 +5,12 @@
 
 #include "rm_types.h"
 
-struct RmDiagDevice {  // accumulator of rm_reduce_counters_device
+struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
     unsigned long long total_sdf;
     unsigned long long total_iters;
     unsigned int max_sdf;
     unsigned int min_sdf;
+    unsigned long long pad;
 };
 
 // Renders rows [y_start, y_end) (runRaymarcher + optional fused shade).
@@ -19,6 +20,9 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream);
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
                            const uint16_t *sdf, const uint16_t *iters, uint8_t *rgba,
                            const float light[3], hipStream_t stream);
+
+// sums 0, max 0, min UINT_MAX
+hipError_t rm_launch_reduce_init(RmDiagDevice *acc, hipStream_t stream);
 
 // diagnostics reduction into *acc (must be initialised: sums 0, max 0, min UINT_MAX)
 hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t n, RmDiagDevice *acc,

@@ -500,6 +500,14 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const 
     }
 }
 
+__global__ void reduce_init_kernel(RmDiagDevice *acc) {
+    acc->total_sdf = 0;
+    acc->total_iters = 0;
+    acc->max_sdf = 0;
+    acc->min_sdf = 0xFFFFFFFFu;
+    acc->pad = 0;
+}
+
 template <int ACCEL>
 __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
                                                        uint32_t *count) {
@@ -541,6 +549,11 @@ hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const ui
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(shade_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, shader, n, depth,
                        normal, sdf, iters, reinterpret_cast<uchar4 *>(rgba), light[0], light[1], light[2]);
+    return hipGetLastError();
+}
+
+hipError_t rm_launch_reduce_init(RmDiagDevice *acc, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, stream, acc);
     return hipGetLastError();
 }
 

@@ -1,0 +1,155 @@
+"""Row-tile sharding of one frame over the GPUs of a node, one process per GPU, and the
+gather of the per-rank tile buffers to rank 0 (RCCL over xGMI through torch.distributed).
+
+Replaces the reference's worker fan-out / fan-in (src/main.ts:444-468): there the rows are
+split in contiguous ceil(H/N) blocks over <= 4 Web Workers and the tiles come back by
+postMessage; here every rank renders its rows of the frame on its own GPU and one
+`gather` moves {RGBA, sdfEval, iters} (8 B/pixel; + depth, normal = 12 B/pixel on request)
+to rank 0.  Pixels are independent functions of (x, y, W, H, camera, scene)
+(raymarcher.ts:72-76,83), so any row subset is exact.
+
+Two partitions:
+  * "contiguous": the reference's rule, rows [min(i r, H), min((i+1) r, H)), r = ceil(H/N).
+    Load-imbalanced: top and bottom blocks are mostly root-box misses.
+  * "interleaved" (default): stripes of `stripe` rows dealt round-robin, rank = (y // stripe) % N.
+A direct gather lets the root receive from its 7 peers over 7 different xGMI links at once;
+a ring would be bound by one link.
+"""
+import numpy as np
+
+from .context import partition_rows
+
+SECTION_BYTES = {"rgba": 4, "sdf": 2, "iters": 2, "depth": 1, "normal": 3}
+
+
+def owned_rows(height, world, rank, mode="interleaved", stripe=16):
+    """List of (y_start, y_end) row ranges of `rank`, in increasing y."""
+    if world <= 1:
+        return [(0, height)] if height > 0 else []
+    if mode == "contiguous":
+        a, b = partition_rows(height, world, rank)
+        return [(a, b)] if b > a else []
+    out = []
+    k = rank
+    while k * stripe < height:
+        out.append((k * stripe, min(height, (k + 1) * stripe)))
+        k += world
+    return out
+
+
+def max_local_rows(height, world, mode="interleaved", stripe=16):
+    return max((sum(b - a for a, b in owned_rows(height, world, r, mode, stripe)) for r in range(world)), default=0)
+
+
+class FrameLayout:
+    """Packed per-rank byte buffer: sections [rgba | sdf | iters | depth | normal], each sized for
+    `cap` rows (the largest share of any rank, so every rank sends the same byte count)."""
+
+    def __init__(self, width, height, world, sections=("rgba", "sdf", "iters"), mode="interleaved", stripe=16):
+        self.width, self.height, self.world = width, height, world
+        self.sections, self.mode, self.stripe = tuple(sections), mode, stripe
+        self.cap = max_local_rows(height, world, mode, stripe)
+        self.offsets = {}
+        off = 0
+        for s in self.sections:
+            self.offsets[s] = off
+            off += (SECTION_BYTES[s] * width * self.cap + 255) // 256 * 256
+        self.nbytes = max(off, 256)
+
+    def rows(self, rank):
+        return owned_rows(self.height, self.world, rank, self.mode, self.stripe)
+
+    def section(self, buf, name, rows=None):
+        """View of one section of a packed uint8 buffer (torch tensor or numpy array)."""
+        n = SECTION_BYTES[name] * self.width * (self.cap if rows is None else rows)
+        return buf[self.offsets[name]:self.offsets[name] + n]
+
+    def scatter_into_frame(self, packed_per_rank, frame):
+        """Rank 0 after the gather: copy every rank's packed rows to their place in the
+        row-major full frame.  frame: dict name -> flat uint8 buffer of H*W*bytes."""
+        W = self.width
+        for r, buf in enumerate(packed_per_rank):
+            local = 0
+            for (a, b) in self.rows(r):
+                for s in self.sections:
+                    bpp = SECTION_BYTES[s]
+                    src = self.section(buf, s)
+                    frame[s][a * W * bpp:b * W * bpp] = src[local * W * bpp:(local + b - a) * W * bpp]
+                local += b - a
+
+
+class ShardedFrameRenderer:
+    """One frame = render the rows this rank owns + gather to rank 0.
+
+    render_rows(y_start, y_end, local_row, packed) must write the tile [y_start, y_end) into the
+    sections of `packed` starting at tile-local row `local_row` (on the GPU: one
+    rm_render_tile_device launch per range; the CPU gloo test injects the oracle)."""
+
+    def __init__(self, layout, rank, world, render_rows, new_buffer, dist=None, double_buffer=True):
+        self.layout, self.rank, self.world = layout, rank, world
+        self.render_rows = render_rows
+        self.dist = dist
+        self.nbuf = 2 if double_buffer else 1
+        self.send = [new_buffer(layout.nbytes) for _ in range(self.nbuf)]
+        self.recv = [[new_buffer(layout.nbytes) for _ in range(world)] if (rank == 0 and world > 1) else None
+                     for _ in range(self.nbuf)]
+        self.work = [None] * self.nbuf
+        self.step = 0
+
+    def render_local(self, slot):
+        local = 0
+        for (a, b) in self.layout.rows(self.rank):
+            self.render_rows(a, b, local, self.send[slot])
+            local += b - a
+
+    def submit(self):
+        """Render this rank's rows for the next frame and start its gather; returns the slot."""
+        slot = self.step % self.nbuf
+        self.step += 1
+        if self.work[slot] is not None:
+            self.work[slot].wait()  # the buffer's previous gather has been consumed
+            self.work[slot] = None
+        self.render_local(slot)
+        if self.world > 1:
+            self.work[slot] = self.dist.gather(self.send[slot], self.recv[slot] if self.rank == 0 else None, dst=0,
+                                               async_op=True)
+        return slot
+
+    def finish(self, slot, frame=None):
+        """Wait for the gather of `slot`; on rank 0 optionally assemble the full frame."""
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        if frame is not None and self.rank == 0:
+            parts = self.recv[slot] if self.world > 1 else [self.send[slot]]
+            self.layout.scatter_into_frame(parts, frame)
+
+    def drain(self):
+        for s in range(self.nbuf):
+            if self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None
+
+
+def new_frame(layout, zeros):
+    """Full-frame buffers for rank 0: dict section -> flat uint8 of H*W*bytes."""
+    return {s: zeros(SECTION_BYTES[s] * layout.width * layout.height) for s in layout.sections}
+
+
+def gpu_render_rows(ctx, scene, width, height, shader, layout):
+    """render_rows callback for the GPU: rm_render_tile_device straight into the packed buffer."""
+    from . import _native as N
+    from .host import _job
+    sh = N.lib().rm_shader_from_string(str(shader).encode())
+    want = set(layout.sections)
+
+    def render_rows(y0, y1, local, packed):
+        W = width
+        def sec(name):
+            if name not in want:
+                return None
+            bpp = SECTION_BYTES[name]
+            return layout.section(packed, name)[local * W * bpp:]
+        job = _job(scene, width, height, 0.0, y0, y1, "sphere-tracer")
+        ctx.render_tile(job, sec("depth"), sec("normal"), sec("sdf"), sec("iters"), rgba=sec("rgba"), shader=sh)
+    return render_rows

@@ -185,6 +185,12 @@ RM_API int rm_reduce_counters(rm_ctx *ctx, const uint16_t *sdf, const uint16_t *
 RM_API int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n,
                                      rm_diagnostics *out, void *stream);
 
+/* Asynchronous form for a frame loop: enqueues init + reduction on `stream` and leaves the
+ * result in device memory `d_acc` (32 bytes: u64 total_sdf, u64 total_iters, u32 max_sdf,
+ * u32 min_sdf, u64 pad); no host synchronisation. */
+RM_API int rm_reduce_counters_enqueue(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n,
+                                      void *d_acc, void *stream);
+
 /* ---- tile partition (main.ts:444-450) ------------------------------------------- */
 
 /* rows of worker i of n: [min(i*r, H), min((i+1)*r, H)) with r = ceil(H / n) */

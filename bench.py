@@ -49,7 +49,8 @@ def cpu_baseline(wl, budget_s=20.0):
     W, H = wl["width"], wl["height"]
     spheres = O.synthetic_spheres(wl["synthetic"]) if "synthetic" in wl else None
     sc = O.OracleScene(preset=wl.get("preset"), accel=wl["accel"], spheres=spheres)
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 64))
+    # 16 = the CPU share of a one-GPU box (the host itself reports every core of the node)
+    cores = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16))
     t0 = time.time()
     probe_rows = list(range(H // 64, H, H // 8))[:8]
     for y in probe_rows:

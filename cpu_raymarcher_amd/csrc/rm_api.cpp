@@ -53,8 +53,11 @@ struct rm_ctx {
     float light[3] = {0, 0, 0};
 
     int64_t opt_tile_w = 8;
-    int64_t opt_filter = 0;
-    int64_t opt_lds = 0;
+    int64_t opt_filter = 1;
+    int64_t opt_lds = 1;
+    int64_t opt_kernel = 2;
+    int64_t opt_list_cap = 32;
+    int64_t opt_coop = 1;
 };
 
 namespace {
@@ -186,6 +189,11 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.tile_w = static_cast<int32_t>(ctx->opt_tile_w);
     p.nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
     p.filter = static_cast<int32_t>(ctx->opt_filter);
+    p.variant = static_cast<int32_t>(ctx->opt_kernel);
+    p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
+    p.coop = static_cast<int32_t>(ctx->opt_coop);
+    p.bvh_prim_count = static_cast<int32_t>(ctx->host.bvh_prims.size());
+    p.oct_prim_count = static_cast<int32_t>(ctx->host.oct_prims.size());
     p.spheres = ctx->dev.spheres;
     p.radii = ctx->dev.radii;
     p.bvh = ctx->dev.bvh;
@@ -526,6 +534,20 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lds = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "kernel")) {
+        if (value != 1 && value != 2) return fail(ctx, RM_E_INVALID, "kernel must be 1 or 2");
+        ctx->opt_kernel = value;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "list_cap")) {
+        if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "list_cap must be in [1, 64]");
+        ctx->opt_list_cap = value;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "coop")) {
+        ctx->opt_coop = value ? 1 : 0;
+        return RM_OK;
+    }
     return fail(ctx, RM_E_INVALID, std::string("unknown option ") + key);
 }
 
@@ -534,6 +556,9 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     if (!std::strcmp(key, "tile_w")) *value = ctx->opt_tile_w;
     else if (!std::strcmp(key, "filter")) *value = ctx->opt_filter;
     else if (!std::strcmp(key, "nodes_in_lds")) *value = ctx->opt_lds;
+    else if (!std::strcmp(key, "kernel")) *value = ctx->opt_kernel;
+    else if (!std::strcmp(key, "list_cap")) *value = ctx->opt_list_cap;
+    else if (!std::strcmp(key, "coop")) *value = ctx->opt_coop;
     else return RM_E_INVALID;
     return RM_OK;
 }

@@ -16,6 +16,9 @@ struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
 // Renders rows [y_start, y_end) (runRaymarcher + optional fused shade).
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream);
 
+// v2 kernel (rm_render_v2.hip); called by rm_launch_render when p.variant == 2
+hipError_t rm_launch_render_v2(const RmRenderParams &p, hipStream_t stream);
+
 // ShadingModel.shade over n = width * height pixels.
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
                            const uint16_t *sdf, const uint16_t *iters, uint8_t *rgba,

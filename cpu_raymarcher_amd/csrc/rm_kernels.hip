@@ -18,61 +18,12 @@
 //   diagnostics                                               main.ts:528-548
 #include <hip/hip_runtime.h>
 
+#include "rm_device.h"
 #include "rm_kernels.h"
 
 namespace {
 
-// ------------------------------------------------------------------ number semantics
-
-__device__ __forceinline__ float to_f32(double v) { return static_cast<float>(v); }  // Float32Array store
-
-// Uint8ClampedArray store: NaN -> 0, clamp, round half to even (v_rndne_f64)
-__device__ __forceinline__ uint8_t u8clamp(double v) {
-    if (!(v > 0.0)) return 0;
-    if (v >= 255.0) return 255;
-    return static_cast<uint8_t>(__builtin_rint(v));
-}
-
-// V8 Math.hypot(x, y, z) for finite binary32-valued inputs: scale by the largest
-// magnitude, Kahan-sum the squares in argument order, sqrt, rescale.  The first Kahan
-// step is folded by hand (sum = 0, compensation = 0 make it exact).
-__device__ __forceinline__ double hypot3(float lx, float ly, float lz) {
-    const double ax = __builtin_fabs(static_cast<double>(lx));
-    const double ay = __builtin_fabs(static_cast<double>(ly));
-    const double az = __builtin_fabs(static_cast<double>(lz));
-    double big = ax > ay ? ax : ay;
-    big = az > big ? az : big;
-    if (big == 0.0) return 0.0;
-    const double nx = ax / big, ny = ay / big, nz = az / big;
-    double sum = nx * nx;
-    const double sy = ny * ny;  // summand - compensation(=0)
-    double next = sum + sy;
-    const double comp = (next - sum) - sy;
-    sum = next;
-    const double sz = nz * nz - comp;
-    sum = sum + sz;
-    return __builtin_sqrt(sum) * big;
-}
-
-struct Vec3f {
-    float x, y, z;
-};
-
-// Primitive.sdf for a translation-only world->local transform: transformMat4 reduces to
-// f32(f64(p - c)), which equals the binary32 subtraction (double rounding is innocuous
-// for +,- when the wide format has >= 2p+2 bits), then Sphere.localSdf.
-__device__ __forceinline__ double sphere_sdf(const RmSphere &s, double radius, const Vec3f &p) {
-    return hypot3(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
-}
-
-// Math.min(candidate, closest) -- operands are never NaN here (inputs validated finite)
-__device__ __forceinline__ double min_dist(double candidate, double closest) {
-    return candidate < closest ? candidate : closest;
-}
-
-__device__ __forceinline__ bool box_contains(const float lo[3], const float hi[3], const Vec3f &p) {
-    return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
-}
+using namespace rmd;
 
 // ------------------------------------------------------------------ Scene.getDistance
 
@@ -155,44 +106,6 @@ __device__ __forceinline__ double scene_distance(const RmRenderParams &P, const 
 
 // ------------------------------------------------------------------ BVH ray intervals
 
-struct Ray {
-    Vec3f o, d;
-};
-
-// BoundingBox.intersectRay (boundingBox.ts:69-105); false = null
-__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const Ray &r, double &tEnter,
-                                     double &tExit) {
-    double tMin = -__builtin_inf(), tMax = __builtin_inf();
-    const float o[3] = {r.o.x, r.o.y, r.o.z};
-    const float d[3] = {r.d.x, r.d.y, r.d.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (__builtin_fabs(static_cast<double>(d[a])) < 1e-10) {
-            if (o[a] < lo[a] || o[a] > hi[a]) return false;
-        } else {
-            const double inv = 1.0 / static_cast<double>(d[a]);
-            double t0 = (static_cast<double>(lo[a]) - static_cast<double>(o[a])) * inv;
-            double t1 = (static_cast<double>(hi[a]) - static_cast<double>(o[a])) * inv;
-            if (t0 > t1) {
-                const double t = t0;
-                t0 = t1;
-                t1 = t;
-            }
-            tMin = tMin > t0 ? tMin : t0;  // Math.max; no NaN possible (|d| >= 1e-10)
-            tMax = tMax < t1 ? tMax : t1;  // Math.min
-            if (tMin > tMax) return false;
-        }
-    }
-    tEnter = tMin;
-    tExit = tMax;
-    return true;
-}
-
-struct Interval {
-    double tEnter, tExit;
-    int ord;  // node index == position in the traversal order of bvh.ts:136-173
-};
-
 // The reference materialises every leaf interval of the ray, stable-sorts them by tEnter
 // (bvh.ts:126-178) and walks the list with an index (bvh.ts:204-240).  This returns the
 // element that follows key (keyT, keyOrd) in exactly that order -- ascending tEnter, ties
@@ -227,99 +140,6 @@ __device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, double 
         i = node.skip;
     }
     return have;
-}
-
-// ------------------------------------------------------------------ Octree empty-space skip
-
-// Octree.marchRay (octree.ts:252-278) for the node that contains the current point.
-// intersectRayBox (octree.ts:195-220) has no zero-direction guard and stores t0/t1 in a
-// Float32Array; 0 * Infinity = NaN then flows through Math.max/min (NaN-propagating) and
-// every comparison with NaN is false, which ends in "return 0".
-__device__ double oct_skip(const RmOctNode &nd, const Ray &r, double t) {
-    if (!nd.is_empty) return 0.0;
-    const float o[3] = {r.o.x, r.o.y, r.o.z};
-    const float d[3] = {r.d.x, r.d.y, r.d.z};
-    float tn[3], tf[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double inv = 1.0 / static_cast<double>(d[a]);
-        double t0 = (static_cast<double>(nd.lo[a]) - static_cast<double>(o[a])) * inv;
-        double t1 = (static_cast<double>(nd.hi[a]) - static_cast<double>(o[a])) * inv;
-        if (inv < 0.0) {
-            const double s = t0;
-            t0 = t1;
-            t1 = s;
-        }
-        tn[a] = to_f32(t0);
-        tf[a] = to_f32(t1);
-    }
-    // JS: tEnter = Math.max(tMin[0..2]), tExit = Math.min(tMax[0..2]) are NaN when any
-    // operand is; `tEnter > tExit || tExit < 0` is false whenever a NaN takes part, and only
-    // tExit is used afterwards, so a NaN tEnter is ignored while a NaN tExit ends in 0.
-    if (tf[0] != tf[0] || tf[1] != tf[1] || tf[2] != tf[2]) return 0.0;
-    float x = tf[0] < tf[1] ? tf[0] : tf[1];
-    x = tf[2] < x ? tf[2] : x;
-    const double tExit = x;
-    if (!(tn[0] != tn[0] || tn[1] != tn[1] || tn[2] != tn[2])) {
-        float e = tn[0] > tn[1] ? tn[0] : tn[1];
-        e = tn[2] > e ? tn[2] : e;
-        if (static_cast<double>(e) > tExit) return 0.0;
-    }
-    if (tExit < 0.0) return 0.0;
-    double toExit = tExit - t;
-    toExit = toExit > 0.0 ? toExit : 0.0;  // Math.max(0, .)
-    const double cap = nd.min_distance * 0.99;
-    double step = toExit < cap ? toExit : cap;
-    step = step > 0.0 ? step : 0.0;
-    return step > 0.0 ? step + 0.001 : 0.0;
-}
-
-// ------------------------------------------------------------------ shading
-
-// ShadingModel.shade for one pixel.  Heatmaps and Normal are pure integer; Phong follows
-// phongModel.ts:33-72 in double with f32 stores.
-__device__ uchar4 shade_pixel(int shader, uint8_t depth, uint8_t n0, uint8_t n1, uint8_t n2, uint16_t sdf,
-                              uint16_t iters, const float light[3]) {
-    if (shader == 2 || shader == 3) {
-        const uint32_t c = shader == 2 ? sdf : iters;
-        const uint32_t k = (c * 5u) & 255u;                       // counter * 5 % 256
-        const uint32_t r = 2u * k < 255u ? 2u * k : 255u;          // Math.min(2k, 255)
-        const uint32_t g = 512u - 2u * k < 255u ? 512u - 2u * k : 255u;  // Math.min(-2k + 512, 255)
-        return make_uchar4(static_cast<uint8_t>(r), static_cast<uint8_t>(g), 0, 255);
-    }
-    if (shader == 1) {
-        if (depth >= 255) return make_uchar4(10, 10, 20, 255);
-        float nx = to_f32(static_cast<double>(n0) / 127.5 - 1.0);
-        float ny = to_f32(static_cast<double>(n1) / 127.5 - 1.0);
-        float nz = to_f32(static_cast<double>(n2) / 127.5 - 1.0);
-        double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
-        if (len > 0) len = 1 / __builtin_sqrt(len);
-        nx = to_f32(nx * len);
-        ny = to_f32(ny * len);
-        nz = to_f32(nz * len);
-        const double ndl = static_cast<double>(nx) * light[0] + static_cast<double>(ny) * light[1] +
-                           static_cast<double>(nz) * light[2];
-        const double diffuse = ndl > 0.0 ? ndl : 0.0;
-        const double k2 = 2 * ndl;
-        float rx = to_f32(nx * k2), ry = to_f32(ny * k2), rz = to_f32(nz * k2);
-        rx = to_f32(static_cast<double>(rx) - light[0]);
-        ry = to_f32(static_cast<double>(ry) - light[1]);
-        rz = to_f32(static_cast<double>(rz) - light[2]);
-        double rl = static_cast<double>(rx) * rx + static_cast<double>(ry) * ry + static_cast<double>(rz) * rz;
-        if (rl > 0) rl = 1 / __builtin_sqrt(rl);
-        rz = to_f32(rz * rl);
-        const double vdr = static_cast<double>(rz);  // dot((0,0,1), reflect)
-        const double base = vdr > 0.0 ? vdr : 0.0;
-        // Math.pow(base, 32): five exact-order squarings would differ from V8's pow in the
-        // last bits; either way the byte below is within 1 LSB (tolerance of the contract)
-        const double spec = 0.5 * pow(base, 32.0);
-        double inten = 0.1 + diffuse + spec;
-        inten = inten < 1.0 ? inten : 1.0;
-        const double color = 255 * inten * (1 - static_cast<double>(depth) / 255);
-        const uint8_t c = u8clamp(color);
-        return make_uchar4(c, c, c, 255);
-    }
-    return make_uchar4(n0, n1, n2, 255);
 }
 
 // ------------------------------------------------------------------ the render kernel
@@ -532,6 +352,7 @@ __global__ __launch_bounds__(256) void hypot_kernel(const float *xyz, int64_t n,
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const int rows = p.y_end - p.y_start;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
+    if (p.variant == 2) return rm_launch_render_v2(p, stream);
     const int tw = p.tile_w, th = 64 / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);

@@ -60,8 +60,14 @@ struct RmRenderParams {
     int32_t bvh_nodes;
     int32_t oct_nodes;
     int32_t tile_w;   // pixels per wave row (64, 32, 16 or 8); wave tile = tile_w x (64 / tile_w)
-    int32_t nodes_in_lds;
-    int32_t filter;   // 1: conservative f32 candidate filter for N-primitive loops
+    int32_t nodes_in_lds;  // 1: kernel stages the node / sphere tables in LDS (host decides)
+    int32_t filter;        // 1: conservative f32 candidate filter for N-primitive loops
+    int32_t variant;       // 1: v1 (one ray per lane, divergent loops); 2: v2 (uniform wave loop)
+    int32_t list_cap;      // v2: per-ray hit-leaf list capacity in LDS (entries of 2 B per lane)
+    int32_t coop;          // v2: wave-cooperative N-primitive fallback
+    int32_t bvh_prim_count;
+    int32_t oct_prim_count;
+    int32_t reserved0;
     const RmSphere *spheres;
     const double *radii;
     const RmBvhNode *bvh;

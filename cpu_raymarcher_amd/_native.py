@@ -81,6 +81,7 @@ SIGNATURES = {
     "rm_reduce_counters_enqueue": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "rm_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rm_selftest_hypot": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "rm_selftest_fastdiv": (C.c_int, [_VP, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
     "rm_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
 }

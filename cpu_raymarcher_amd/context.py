@@ -147,6 +147,16 @@ class Context:
         return out
 
 
+def _selftest_fastdiv(self, seed, n):
+    """Device-side comparison of the two Math.hypot forms; returns the mismatch count."""
+    out = C.c_uint64(0)
+    N.check(self._h, N.lib().rm_selftest_fastdiv(self._h, int(seed), int(n), C.byref(out)))
+    return out.value
+
+
+Context.selftest_fastdiv = _selftest_fastdiv
+
+
 def camera_from_angles(pitch, yaw):
     rot = np.zeros(9, np.float32)
     org = np.zeros(3, np.float32)

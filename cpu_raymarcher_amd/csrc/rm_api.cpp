@@ -519,6 +519,23 @@ int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out) {
     return RM_OK;
 }
 
+int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (n < 0) return fail(ctx, RM_E_INVALID, "negative count");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, 256);
+    if (rc) return rc;
+    unsigned long long *d = static_cast<unsigned long long *>(ctx->scratch);
+    RM_HIP(ctx, hipMemsetAsync(d, 0, sizeof *d, ctx->stream));
+    RM_HIP(ctx, rm_launch_fastdiv_selftest(seed, n, d, ctx->stream));
+    unsigned long long h = 0;
+    RM_HIP(ctx, hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = h;
+    return RM_OK;
+}
+
 int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return RM_E_INVALID;
     if (!std::strcmp(key, "tile_w")) {

@@ -345,7 +345,52 @@ __global__ __launch_bounds__(256) void hypot_kernel(const float *xyz, int64_t n,
     out[i] = hypot3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
 }
 
+// hypot3 (compiler's IEEE division) vs hypot3_shared_rcp on counter-generated binary32
+// triples: random mantissas, exponents spread over [2^-149, 2^60], zeros, equal and
+// near-equal magnitudes.  Counts bitwise mismatches.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float gen_f32(uint64_t r, int mode) {
+    const uint32_t mant = static_cast<uint32_t>(r) & 0x7FFFFFu;
+    const uint32_t sign = static_cast<uint32_t>(r >> 63) << 31;
+    uint32_t exp;
+    const uint32_t sel = static_cast<uint32_t>(r >> 40) & 0xFFu;
+    if (mode == 0) exp = 96 + sel % 64;        // around 1: 2^-31 .. 2^32
+    else if (mode == 1) exp = sel % 188;       // whole low range incl. denormals (exp 0)
+    else exp = 120 + sel % 10;                 // same binade neighbourhood
+    if ((r >> 50 & 0x3F) == 0) return __uint_as_float(sign);  // +-0
+    return __uint_as_float(sign | (exp << 23) | mant);
+}
+
+__global__ __launch_bounds__(256) void fastdiv_selftest_kernel(uint64_t seed, int64_t n, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t base = seed + 3ull * static_cast<uint64_t>(i);
+        const int mode = static_cast<int>(i % 3);
+        float a = gen_f32(mix64(base), mode), b = gen_f32(mix64(base + 1), mode), c = gen_f32(mix64(base + 2), mode);
+        if ((i & 15) == 7) b = a;                     // equal magnitudes: quotient exactly 1
+        if ((i & 31) == 19) c = -a;
+        if ((i & 63) == 33) b = __uint_as_float(__float_as_uint(a) + 1);  // one ulp apart
+        const double x = hypot3(a, b, c), y = hypot3_shared_rcp(a, b, c);
+        if (__double_as_longlong(x) != __double_as_longlong(y)) bad++;
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
+
+hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long long *d_mismatches, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fastdiv_selftest_kernel, dim3(2048), dim3(256), 0, stream, seed, n, d_mismatches);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------- launchers
 

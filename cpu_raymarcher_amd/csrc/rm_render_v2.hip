@@ -83,7 +83,7 @@ __device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int 
         float err;
         const float a = sphere_sdf_estimate(s, p, err);
         if (a - err <= ub) {
-            const double e = sphere_sdf(s, S.radii[id], p);
+            const double e = sphere_sdf_fast(s, S.radii[id], p);
             if (e < closest) {
                 closest = e;
                 ub = f32_upper(e);
@@ -96,7 +96,7 @@ __device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int 
 __device__ double lane_min_exact(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest) {
     for (int k = 0; k < n; ++k) {
         const int id = ids ? ids[k] : k;
-        closest = min_dist(sphere_sdf(S.spheres[id], S.radii[id], p), closest);
+        closest = min_dist(sphere_sdf_fast(S.spheres[id], S.radii[id], p), closest);
     }
     return closest;
 }
@@ -116,7 +116,7 @@ __device__ double coop_all_prims(const SceneView &S, const Vec3f &b, int lane) {
         const RmSphere s = S.spheres[j];
         float err;
         const float a = sphere_sdf_estimate(s, b, err);
-        if (a - err <= ub) best = min_dist(sphere_sdf(s, S.radii[j], b), best);
+        if (a - err <= ub) best = min_dist(sphere_sdf_fast(s, S.radii[j], b), best);
     }
     return wave_min_f64(best);
 }
@@ -144,7 +144,7 @@ __device__ double all_prims_wave(const SceneView &S, bool need, const Vec3f &q, 
             if (lane == src) closest = r;
         }
     } else if (need) {
-        closest = (filter && n > 4) ? lane_min_filtered(S, nullptr, n, q, closest) : lane_min_exact(S, nullptr, n, q, closest);
+        closest = (filter && n >= 2) ? lane_min_filtered(S, nullptr, n, q, closest) : lane_min_exact(S, nullptr, n, q, closest);
     }
     return closest;
 }
@@ -168,10 +168,8 @@ __device__ double bvh_distance_wave(const SceneView &S, bool need, const Vec3f &
                 continue;
             }
             const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
-            for (int k = 0; k < cnt; ++k) {
-                const int id = S.bvh_prims[first + k];
-                closest = min_dist(sphere_sdf(S.spheres[id], S.radii[id], q), closest);
-            }
+            closest = (filter && cnt >= 2) ? lane_min_filtered(S, S.bvh_prims + first, cnt, q, closest)
+                                           : lane_min_exact(S, S.bvh_prims + first, cnt, q, closest);
             found += static_cast<uint32_t>(cnt);
             i = node.skip;
         }
@@ -204,14 +202,14 @@ __device__ __forceinline__ int oct_find(const SceneView &S, const Vec3f &p) {
 __device__ double oct_distance_lane(const SceneView &S, int node, const Vec3f &q, uint32_t &count, bool filter) {
     if (node < 0) {  // outside the cube: all primitives (scene.ts:166,183-189)
         count += static_cast<uint32_t>(S.n_prims);
-        return (filter && S.n_prims > 4) ? lane_min_filtered(S, nullptr, S.n_prims, q, RM_MAX_DIST)
+        return (filter && S.n_prims >= 2) ? lane_min_filtered(S, nullptr, S.n_prims, q, RM_MAX_DIST)
                                          : lane_min_exact(S, nullptr, S.n_prims, q, RM_MAX_DIST);
     }
     const RmOctNode nd = S.oct[node];
     double closest = RM_MAX_DIST;
     if (nd.prim_count > 0) {
         const int32_t *ids = S.oct_prims + nd.prim_first;
-        closest = (filter && nd.prim_count > 4) ? lane_min_filtered(S, ids, nd.prim_count, q, closest)
+        closest = (filter && nd.prim_count >= 2) ? lane_min_filtered(S, ids, nd.prim_count, q, closest)
                                                 : lane_min_exact(S, ids, nd.prim_count, q, closest);
         count += static_cast<uint32_t>(nd.prim_count);
     } else if (nd.is_empty) {

@@ -202,6 +202,11 @@ RM_API int rm_partition_rows(int32_t height, int32_t n_workers, int32_t i, int32
 /* V8 Math.hypot of n float triples evaluated by the device code path used in Sphere.sdf */
 RM_API int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out);
 
+/* Device check of the shared-reciprocal division used by the v2 kernel's sphere SDF: evaluates
+ * Math.hypot with the compiler's IEEE divisions and with the shared reciprocal on n generated
+ * binary32 triples (zeros, denormals, equal magnitudes included) and counts bitwise mismatches. */
+RM_API int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *mismatches);
+
 /* kernel-variant knobs for measurement (tile shape, LDS staging ...); unknown keys are
  * RM_E_INVALID.  Never changes results. */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);

@@ -57,6 +57,34 @@ def test_device_hypot_is_v8_math_hypot(rm, gpu_ctx, oracle):
     assert np.array_equal(got[sel], want)
 
 
+def test_shared_reciprocal_division_is_bit_identical(gpu_ctx):
+    """v2's sphere SDF shares one reciprocal refinement between the three divisions of
+    Math.hypot; on 3e8 generated triples it must never differ from the IEEE divisions."""
+    assert gpu_ctx.selftest_fastdiv(0x1234, 300_000_000) == 0
+    assert gpu_ctx.selftest_fastdiv(0xBEEF, 50_000_000) == 0
+
+
+def test_v1_and_v2_kernels_agree(rm, oracle):
+    """Two independently structured kernels (divergent per-ray loops with native divisions vs
+    the uniform wave loop with lists / cooperative fallback / shared reciprocal) must produce
+    the same bytes, with every option combination."""
+    ctx = rm.Context(0)
+    sp = oracle.synthetic_spheres(3000)
+    for preset, accel, spheres in [(3, "BVH", None), (3, "Octree", None), (3, "None", None), (None, "BVH", sp),
+                                   (None, "Octree", sp)]:
+        outs = []
+        for opts in [dict(kernel=1), dict(kernel=2), dict(kernel=2, coop=0), dict(kernel=2, filter=0, coop=0),
+                     dict(kernel=2, nodes_in_lds=0), dict(kernel=2, list_cap=2), dict(kernel=2, tile_w=64)]:
+            for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8).items():
+                ctx.set_option(k, v)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            outs.append(gpu_render(rm, ctx, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres))
+        for o in outs[1:]:
+            assert_same(o, outs[0], "%s %s variants" % (preset, accel))
+        assert_same(outs[0], cpu_render(oracle, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres), "vs oracle")
+
+
 @pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
 def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):

@@ -27,6 +27,8 @@ struct DeviceScene {
     int32_t *bvh_prims = nullptr;
     RmOctNode *oct = nullptr;
     int32_t *oct_prims = nullptr;
+    uint32_t *pq_cells = nullptr;
+    uint16_t *pq_list = nullptr;
 };
 
 }  // namespace
@@ -52,12 +54,19 @@ struct rm_ctx {
     RmDiagDevice *d_diag = nullptr;
     float light[3] = {0, 0, 0};
 
-    int64_t opt_tile_w = 8;
+    int64_t opt_tile_w = 16;
     int64_t opt_filter = 1;
     int64_t opt_lds = 1;
-    int64_t opt_kernel = 2;
+    int64_t opt_kernel = 0;  // 0 = auto: v2 for BVH / no acceleration, v1 for the octree (measured faster)
     int64_t opt_list_cap = 32;
     int64_t opt_coop = 1;
+    int64_t opt_grid = 1;
+    int64_t opt_blocks_per_cu = 3;
+    int64_t opt_refill = 64;
+    int64_t opt_hw_xcd = 1;
+    unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
+    unsigned int counter_slot = 0;
+    int num_cus = 256;
 };
 
 namespace {
@@ -86,6 +95,8 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.bvh_prims);
     (void)hipFree(d.oct);
     (void)hipFree(d.oct_prims);
+    (void)hipFree(d.pq_cells);
+    (void)hipFree(d.pq_list);
     d = DeviceScene();
 }
 
@@ -110,6 +121,8 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.bvh_prims, &ctx->dev.bvh_prims))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct, &ctx->dev.oct))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_prims, &ctx->dev.oct_prims))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.pq_cells, &ctx->dev.pq_cells))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.pq_list, &ctx->dev.pq_list))) return rc;
     return RM_OK;
 }
 
@@ -182,6 +195,11 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.y_end = job->y_end;
     rmh::camera_from_angles(job->camera_pitch, job->camera_yaw, p.rot, p.origin);
     std::memcpy(p.light, ctx->light, sizeof p.light);
+    for (int k = 0; k < 9; ++k) p.rot_d[k] = p.rot[k];
+    for (int k = 0; k < 3; ++k) {
+        p.origin_d[k] = p.origin[k];
+        p.light_d[k] = p.light[k];
+    }
     p.n_prims = static_cast<int32_t>(ctx->host.spheres.size());
     p.accel = ctx->host.accel;
     p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
@@ -190,10 +208,26 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
     p.filter = static_cast<int32_t>(ctx->opt_filter);
     p.variant = static_cast<int32_t>(ctx->opt_kernel);
+    if (p.variant == 0) p.variant = ctx->host.accel == RM_ACCEL_OCTREE ? 1 : 2;
     p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
     p.coop = static_cast<int32_t>(ctx->opt_coop);
     p.bvh_prim_count = static_cast<int32_t>(ctx->host.bvh_prims.size());
     p.oct_prim_count = static_cast<int32_t>(ctx->host.oct_prims.size());
+    p.blocks_per_cu = static_cast<int32_t>(ctx->opt_blocks_per_cu);
+    p.num_cus = ctx->num_cus;
+    p.refill_threshold = static_cast<int32_t>(ctx->opt_refill);
+    p.hw_xcd = static_cast<int32_t>(ctx->opt_hw_xcd);
+    p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 64) : nullptr;
+    for (int k = 0; k < 3; ++k) {
+        p.pq_dim[k] = ctx->host.pq_dim[k];
+        p.pq_origin[k] = ctx->host.pq_origin[k];
+        p.pq_inv[k] = ctx->host.pq_inv[k];
+    }
+    p.pq_cell_count = static_cast<int32_t>(ctx->host.pq_cells.size());
+    p.pq_list_count = static_cast<int32_t>(ctx->host.pq_list.size());
+    p.use_grid = (ctx->opt_grid && !ctx->host.pq_cells.empty()) ? 1 : 0;
+    p.pq_cells = ctx->dev.pq_cells;
+    p.pq_list = ctx->dev.pq_list;
     p.spheres = ctx->dev.spheres;
     p.radii = ctx->dev.radii;
     p.bvh = ctx->dev.bvh;
@@ -227,12 +261,16 @@ int rm_create(int device, rm_ctx **out) {
         e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 64 * 8 * sizeof(unsigned int));
         if (e != hipSuccess) {
             delete ctx;
             return RM_E_HIP;
         }
         ctx->device = device;
         ctx->has_device = true;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            ctx->num_cus = cus;
     }
     *out = ctx;
     return RM_OK;
@@ -246,6 +284,7 @@ void rm_destroy(rm_ctx *ctx) {
         free_device_scene(ctx);
         (void)hipFree(ctx->scratch);
         (void)hipFree(ctx->d_diag);
+        (void)hipFree(ctx->d_counters);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -552,7 +591,7 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         return RM_OK;
     }
     if (!std::strcmp(key, "kernel")) {
-        if (value != 1 && value != 2) return fail(ctx, RM_E_INVALID, "kernel must be 1 or 2");
+        if (value < 0 || value > 2) return fail(ctx, RM_E_INVALID, "kernel must be 0 (auto), 1 or 2");
         ctx->opt_kernel = value;
         return RM_OK;
     }
@@ -563,6 +602,24 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "coop")) {
         ctx->opt_coop = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "refill")) {
+        if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "refill must be in [1, 64]");
+        ctx->opt_refill = value;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "hw_xcd")) {
+        ctx->opt_hw_xcd = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "grid")) {
+        ctx->opt_grid = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "blocks_per_cu")) {
+        if (value < 1 || value > 8) return fail(ctx, RM_E_INVALID, "blocks_per_cu must be in [1, 8]");
+        ctx->opt_blocks_per_cu = value;
         return RM_OK;
     }
     return fail(ctx, RM_E_INVALID, std::string("unknown option ") + key);
@@ -576,6 +633,10 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "kernel")) *value = ctx->opt_kernel;
     else if (!std::strcmp(key, "list_cap")) *value = ctx->opt_list_cap;
     else if (!std::strcmp(key, "coop")) *value = ctx->opt_coop;
+    else if (!std::strcmp(key, "grid")) *value = ctx->opt_grid;
+    else if (!std::strcmp(key, "refill")) *value = ctx->opt_refill;
+    else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
+    else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;
     else return RM_E_INVALID;
     return RM_OK;
 }

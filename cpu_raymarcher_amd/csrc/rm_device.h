@@ -85,6 +85,8 @@ struct Vec3f {
 
 struct Ray {
     Vec3f o, d;
+    double od[3];  // origin again as doubles, supplied by the host: wave-uniform values stay in
+                   // SGPRs instead of being widened per lane (v_cvt_f64_f32) and hoisted into VGPRs
 };
 
 // Primitive.sdf (primitive.ts:33-39) for a translation-only world->local transform:
@@ -131,8 +133,8 @@ __device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const
             if (o[a] < lo[a] || o[a] > hi[a]) return false;
         } else {
             const double inv = 1.0 / static_cast<double>(d[a]);
-            double t0 = (static_cast<double>(lo[a]) - static_cast<double>(o[a])) * inv;
-            double t1 = (static_cast<double>(hi[a]) - static_cast<double>(o[a])) * inv;
+            double t0 = (static_cast<double>(lo[a]) - r.od[a]) * inv;
+            double t1 = (static_cast<double>(hi[a]) - r.od[a]) * inv;
             if (t0 > t1) {
                 const double t = t0;
                 t0 = t1;
@@ -175,8 +177,8 @@ __device__ __forceinline__ bool slab_inv(const float lo[3], const float hi[3], c
         if (ri.par[a]) {
             if (o[a] < lo[a] || o[a] > hi[a]) return false;
         } else {
-            double t0 = (static_cast<double>(lo[a]) - static_cast<double>(o[a])) * ri.inv[a];
-            double t1 = (static_cast<double>(hi[a]) - static_cast<double>(o[a])) * ri.inv[a];
+            double t0 = (static_cast<double>(lo[a]) - r.od[a]) * ri.inv[a];
+            double t1 = (static_cast<double>(hi[a]) - r.od[a]) * ri.inv[a];
             if (t0 > t1) {
                 const double t = t0;
                 t0 = t1;
@@ -203,14 +205,13 @@ struct Interval {
 // every comparison with NaN is false.
 __device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, double t) {
     if (!nd.is_empty) return 0.0;
-    const float o[3] = {r.o.x, r.o.y, r.o.z};
     const float d[3] = {r.d.x, r.d.y, r.d.z};
     float tn[3], tf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const double inv = 1.0 / static_cast<double>(d[a]);
-        double t0 = (static_cast<double>(nd.lo[a]) - static_cast<double>(o[a])) * inv;
-        double t1 = (static_cast<double>(nd.hi[a]) - static_cast<double>(o[a])) * inv;
+        double t0 = (static_cast<double>(nd.lo[a]) - r.od[a]) * inv;
+        double t1 = (static_cast<double>(nd.hi[a]) - r.od[a]) * inv;
         if (inv < 0.0) {
             const double s = t0;
             t0 = t1;
@@ -247,9 +248,9 @@ __device__ __forceinline__ Ray make_ray(const RmRenderParams &P, int x, int y) {
     const double v = (static_cast<double>(y) / static_cast<double>(P.height) - 0.5) * 2.0;
     const double u = (static_cast<double>(x) / static_cast<double>(P.width) - 0.5) * 2.0;
     const double ax = to_f32(u), ay = to_f32(v), az = -1.0;
-    const float dx = to_f32(ax * P.rot[0] + ay * P.rot[3] + az * P.rot[6]);
-    const float dy = to_f32(ax * P.rot[1] + ay * P.rot[4] + az * P.rot[7]);
-    const float dz = to_f32(ax * P.rot[2] + ay * P.rot[5] + az * P.rot[8]);
+    const float dx = to_f32(ax * P.rot_d[0] + ay * P.rot_d[3] + az * P.rot_d[6]);
+    const float dy = to_f32(ax * P.rot_d[1] + ay * P.rot_d[4] + az * P.rot_d[7]);
+    const float dz = to_f32(ax * P.rot_d[2] + ay * P.rot_d[5] + az * P.rot_d[8]);
     double len = static_cast<double>(dx) * dx + static_cast<double>(dy) * dy + static_cast<double>(dz) * dz;
     if (len > 0) len = 1 / __builtin_sqrt(len);
     Ray ray;
@@ -259,15 +260,18 @@ __device__ __forceinline__ Ray make_ray(const RmRenderParams &P, int x, int y) {
     ray.o.x = P.origin[0];
     ray.o.y = P.origin[1];
     ray.o.z = P.origin[2];
+    ray.od[0] = P.origin_d[0];
+    ray.od[1] = P.origin_d[1];
+    ray.od[2] = P.origin_d[2];
     return ray;
 }
 
 // vec3.scaleAndAdd(out, origin, dir, t) (sphereTracer.ts:44-45, raymarcher.ts:94-95)
 __device__ __forceinline__ Vec3f point_at(const Ray &r, double t) {
     Vec3f p;
-    p.x = to_f32(static_cast<double>(r.o.x) + static_cast<double>(r.d.x) * t);
-    p.y = to_f32(static_cast<double>(r.o.y) + static_cast<double>(r.d.y) * t);
-    p.z = to_f32(static_cast<double>(r.o.z) + static_cast<double>(r.d.z) * t);
+    p.x = to_f32(r.od[0] + static_cast<double>(r.d.x) * t);
+    p.y = to_f32(r.od[1] + static_cast<double>(r.d.y) * t);
+    p.z = to_f32(r.od[2] + static_cast<double>(r.d.z) * t);
     return p;
 }
 
@@ -275,7 +279,7 @@ __device__ __forceinline__ Vec3f point_at(const Ray &r, double t) {
 // and Normal (normalModel.ts:21-24) are pure integer; Phong follows phongModel.ts:33-72 in
 // double with f32 stores.
 __device__ __forceinline__ uchar4 shade_pixel(int shader, uint8_t depth, uint8_t n0, uint8_t n1, uint8_t n2,
-                                              uint16_t sdf, uint16_t iters, const float light[3]) {
+                                              uint16_t sdf, uint16_t iters, const double light[3]) {
     if (shader == 2 || shader == 3) {
         const uint32_t c = shader == 2 ? sdf : iters;
         const uint32_t k = (c * 5u) & 255u;                              // counter * 5 % 256
@@ -334,7 +338,7 @@ __device__ __forceinline__ void store_pixel(const RmRenderParams &P, size_t idx,
     }
     if (P.sdf) P.sdf[idx] = c16;
     if (P.iters) P.iters[idx] = i16;
-    if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, n0, n1, n2, c16, i16, P.light);
+    if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, n0, n1, n2, c16, i16, P.light_d);
 }
 
 // vec3.normalize (raymarcher.ts:133)

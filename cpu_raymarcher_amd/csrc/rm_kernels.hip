@@ -261,6 +261,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     ray.o.x = P.origin[0];
     ray.o.y = P.origin[1];
     ray.o.z = P.origin[2];
+    ray.od[0] = P.origin_d[0];
+    ray.od[1] = P.origin_d[1];
+    ray.od[2] = P.origin_d[2];
 
     uint32_t count = 0, iters = 0;
     const double depth = ray_march<ACCEL>(P, ray, count, iters);
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     }
     if (P.sdf) P.sdf[idx] = c16;
     if (P.iters) P.iters[idx] = i16;
-    if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light);
+    if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light_d);
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
 __global__ __launch_bounds__(256) void shade_kernel(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
                                                     const uint16_t *sdf, const uint16_t *iters, uchar4 *rgba, float l0,
                                                     float l1, float l2) {
-    const float light[3] = {l0, l1, l2};
+    const double light[3] = {l0, l1, l2};
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         rgba[i] = shade_pixel(shader, depth[i], normal[3 * i], normal[3 * i + 1], normal[3 * i + 2], sdf[i], iters[i],

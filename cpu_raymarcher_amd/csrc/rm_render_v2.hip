@@ -42,6 +42,8 @@ struct SceneView {
     const int32_t *oct_prims;
     const RmSphere *spheres;
     const double *radii;
+    const uint32_t *pq_cells;
+    const uint16_t *pq_list;
     int n_prims, bvh_nodes;
 };
 
@@ -150,11 +152,37 @@ __device__ double all_prims_wave(const SceneView &S, bool need, const Vec3f &q, 
 }
 
 // BVH branch of Scene.getDistance (scene.ts:167-181); whole wave must call
-__device__ double bvh_distance_wave(const SceneView &S, bool need, const Vec3f &q, uint32_t &count, int lane, bool coop,
-                                    bool filter) {
+__device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
+                                    uint32_t &count, int lane, bool coop, bool filter, bool use_grid) {
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
-    if (need) {
+    bool walk_tree = false;
+    if (need && use_grid) {
+        // BVH.getPrimitivesAt through the leaf grid: the leaves listed for p's cell are a superset
+        // of the leaves whose box contains p; each is re-tested with the reference's inclusive
+        // f32 compares.  Outside the root box no leaf can contain p.
+        const RmBvhNode root = S.nodes[0];
+        if (box_contains(root.lo, root.hi, q)) {
+            const int cx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
+            const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
+            const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
+            const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
+            const int ccnt = static_cast<int>(cell & 0xFFu);
+            if (ccnt == 255) walk_tree = true;  // crowded cell: fall back to the tree walk below
+            else {
+                const uint16_t *lst = S.pq_list + (cell >> 8);
+                for (int e = 0; e < ccnt; ++e) {
+                    const RmBvhNode node = S.nodes[lst[e]];
+                    if (!box_contains(node.lo, node.hi, q)) continue;
+                    const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
+                    closest = (filter && cnt >= 2) ? lane_min_filtered(S, S.bvh_prims + first, cnt, q, closest)
+                                                   : lane_min_exact(S, S.bvh_prims + first, cnt, q, closest);
+                    found += static_cast<uint32_t>(cnt);
+                }
+            }
+        }
+    }
+    if (need && (!use_grid || walk_tree)) {
         int i = 0;
         const int n = S.bvh_nodes;
         while (i < n) {  // BVH.getPrimitivesAt (bvh.ts:95-121), stackless
@@ -193,7 +221,7 @@ __device__ __forceinline__ int oct_find(const SceneView &S, const Vec3f &p) {
     for (;;) {
         const int first = nodes[i].first_child;
         if (first < 0) return i;
-        const float cx = nodes[first].hi[0], cy = nodes[first].hi[1], cz = nodes[first].hi[2];
+        const float cx = nodes[i].center[0], cy = nodes[i].center[1], cz = nodes[i].center[2];
         i = first + (p.x > cx ? 1 : 0) + (p.y > cy ? 2 : 0) + (p.z > cz ? 4 : 0);
     }
 }
@@ -326,19 +354,36 @@ __device__ __forceinline__ const T *stage(unsigned char *smem, size_t &off, cons
     return dst;
 }
 
+// Wave-granular work queue: a work item is one 256-pixel tile (tile_w wide, 256 / tile_w tall).
+// XCD x owns the tile rows r with r % 8 == x, so the partial-line stores of horizontally
+// adjacent tiles meet in one L2; a wave whose XCD queue is empty steals from the others.
+struct TileQueue {
+    unsigned int *counters;  // one per XCD, zeroed by the host before the launch
+    int tiles_x, tiles_y, tile_w, tile_h;
+};
+
+// next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
+__device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &tile_col, int &tile_row, int lane) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int x = (home + attempt) & 7;
+        unsigned int k = 0;
+        if (lane == 0) k = atomicAdd(&Q.counters[x], 1u);
+        k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
+        const int row = static_cast<int>(k / static_cast<unsigned int>(Q.tiles_x)) * 8 + x;
+        if (row < Q.tiles_y) {
+            tile_row = row;
+            tile_col = static_cast<int>(k % static_cast<unsigned int>(Q.tiles_x));
+            home = x;
+            return true;
+        }
+    }
+    return false;
+}
+
 template <int ACCEL, bool LDS>
 __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // XCD-aware tile order: blocks with equal (blockIdx % 8) walk along one tile row
-    const int tw = P.tile_w, th = 64 / tw;
-    const int rows = P.y_end - P.y_start;
-    const int tiles_x = (P.width + tw - 1) / tw;
-    const int tiles_y = (rows + 4 * th - 1) / (4 * th);
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int tile_row = (k / tiles_x) * 8 + xcd, tile_col = k % tiles_x;
-    if (tile_row >= tiles_y) return;  // whole workgroup
 
     SceneView S;
     S.nodes = P.bvh;
@@ -347,13 +392,20 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     S.oct_prims = P.oct_prims;
     S.spheres = P.spheres;
     S.radii = P.radii;
+    S.pq_cells = P.pq_cells;
+    S.pq_list = P.pq_list;
     S.n_prims = P.n_prims;
     S.bvh_nodes = P.bvh_nodes;
+    const bool use_grid = ACCEL == 2 && P.use_grid != 0;
     size_t off = 0;
-    if (LDS) {
+    if (LDS) {  // staged once per persistent workgroup
         if (ACCEL == 2) {
             S.nodes = stage(smem, off, P.bvh, P.bvh_nodes);
             S.bvh_prims = stage(smem, off, P.bvh_prims, P.bvh_prim_count);
+            if (use_grid) {
+                S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
+                S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
+            }
         } else if (ACCEL == 1) {
             S.oct = stage(smem, off, P.oct, P.oct_nodes);
             S.oct_prims = stage(smem, off, P.oct_prims, P.oct_prim_count);
@@ -367,18 +419,31 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     L.cap = P.list_cap;
     L.cnt = 0;
     L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
-
-    const int x = tile_col * tw + (lane % tw);
-    const int row = tile_row * (4 * th) + wave * th + (lane / tw);  // tile-local row
-    const bool active = x < P.width && row < rows;
-    const int y = P.y_start + row;
-    const size_t idx = static_cast<size_t>(row) * P.width + x;
     const bool coop = P.coop != 0, filter = P.filter != 0;
 
-    Ray ray = make_ray(P, active ? x : 0, active ? y : P.y_start);
+    TileQueue Q;
+    Q.counters = P.tile_counters;
+    Q.tile_w = P.tile_w;
+    Q.tile_h = 256 / P.tile_w;
+    const int rows = P.y_end - P.y_start;
+    Q.tiles_x = (P.width + Q.tile_w - 1) / Q.tile_w;
+    Q.tiles_y = (rows + Q.tile_h - 1) / Q.tile_h;
+    // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
+    int home = P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7);
+    const int refill_at = P.refill_threshold;  // refill as soon as this many lanes are idle
+
+    // ---- wave state: the tile being consumed ------------------------------------------------
+    int tile_col = 0, tile_row = 0, qpos = 256;  // qpos: next pixel of the current tile (256 = used up)
+    bool no_more = false;
+
+    // ---- lane state ------------------------------------------------------------------------
+    Ray ray = make_ray(P, 0, P.y_start);
     RayInv ri;
+    if (ACCEL == 2) ri = make_ray_inv(ray);
     uint32_t count = 0, iters = 0;
-    int phase = active ? PH_MARCH : PH_DONE;
+    int phase = PH_DONE;
+    bool have_pixel = false;
+    int px = 0, prow = 0;  // pixel column, tile-local row of the lane's pixel
     int loopi = 0;
     double t = 0.0, depth = RM_MAX_DIST, d0 = 0.0;
     float nx = 0.f, ny = 0.f, nz = 0.f;
@@ -389,17 +454,6 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     cur.ord = -1;
     bool haveCur = false;
 
-    if (ACCEL == 2) {
-        ri = make_ray_inv(ray);
-        if (active) {
-            haveCur = bvh_prologue(S, ray, ri, L, cur);
-            if (!haveCur) {  // bvh.ts:190-192 -> sphereTracer.ts:38-40: exactly MAX_DIST, zero normal
-                depth = RM_MAX_DIST;
-                phase = PH_DONE;
-            }
-        }
-    }
-
     // march finished with distance `dist_total` (raymarcher.ts:91-102)
     auto finish_march = [&](double dist_total) {
         depth = dist_total;
@@ -408,6 +462,54 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     };
 
     for (;;) {
+        // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
+        // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
+        const unsigned long long idle = __ballot(phase == PH_DONE);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= refill_at || n_idle == 64) {
+            if (phase == PH_DONE && have_pixel) {
+                store_pixel(P, static_cast<size_t>(prow) * P.width + px, depth, nx, ny, nz, count, iters);
+                have_pixel = false;
+            }
+            if (!no_more && qpos >= 256) {
+                if (pull_tile(Q, home, tile_col, tile_row, lane)) qpos = 0;
+                else no_more = true;
+            }
+            if (!no_more) {
+                const int remaining = 256 - qpos;
+                const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(idle >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(idle), 0u));
+                const bool take = phase == PH_DONE && rank < remaining;
+                if (take) {
+                    const int n = qpos + rank;  // pixel n of the tile, in 64-pixel sub-tile order
+                    const int sub = n >> 6, l = n & 63;
+                    px = tile_col * Q.tile_w + (l % Q.tile_w);
+                    prow = tile_row * Q.tile_h + sub * (64 / Q.tile_w) + (l / Q.tile_w);
+                    if (px < P.width && prow < rows) {
+                        have_pixel = true;
+                        ray = make_ray(P, px, P.y_start + prow);
+                        count = 0;
+                        iters = 0;
+                        loopi = 0;
+                        t = 0.0;
+                        depth = RM_MAX_DIST;
+                        nx = ny = nz = 0.f;
+                        phase = PH_MARCH;
+                        if (ACCEL == 2) {
+                            ri = make_ray_inv(ray);
+                            haveCur = bvh_prologue(S, ray, ri, L, cur);
+                            if (!haveCur) phase = PH_DONE;  // bvh.ts:190-192: exactly MAX_DIST, zero normal
+                        }
+                    }
+                }
+                qpos += n_idle < remaining ? n_idle : remaining;
+            }
+        }
+        if (no_more && !__any(phase != PH_DONE)) {
+            if (have_pixel) store_pixel(P, static_cast<size_t>(prow) * P.width + px, depth, nx, ny, nz, count, iters);
+            break;
+        }
+
         // ---- A: bookkeeping until this lane needs a distance (sphereTracer.ts:43-64) ------
         bool need = false;
         Vec3f q = {0.f, 0.f, 0.f};
@@ -472,11 +574,11 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
             if (ACCEL == 1) onode = oct_find(S, q);
             need = true;
         }
-        if (!__any(need)) break;
+        if (!__any(need)) continue;  // every live ray just finished: go and refill
 
         // ---- B: one Scene.getDistance per needing lane --------------------------------------
         double dist;
-        if (ACCEL == 2) dist = bvh_distance_wave(S, need, q, count, lane, coop, filter);
+        if (ACCEL == 2) dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid);
         else if (ACCEL == 1) dist = need ? oct_distance_lane(S, onode, q, count, filter) : RM_MAX_DIST;
         else {
             dist = all_prims_wave(S, need, q, lane, coop, filter);
@@ -505,14 +607,17 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
             }
         }
     }
-    if (active) store_pixel(P, idx, depth, nx, ny, nz, count, iters);
 }
 
 size_t scene_lds_bytes(const RmRenderParams &p) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t b = 0;
-    if (p.accel == 2) b += up(static_cast<size_t>(p.bvh_nodes) * sizeof(RmBvhNode)) + up(static_cast<size_t>(p.bvh_prim_count) * 4);
-    else if (p.accel == 1) b += up(static_cast<size_t>(p.oct_nodes) * sizeof(RmOctNode)) + up(static_cast<size_t>(p.oct_prim_count) * 4);
+    if (p.accel == 2) {
+        b += up(static_cast<size_t>(p.bvh_nodes) * sizeof(RmBvhNode)) + up(static_cast<size_t>(p.bvh_prim_count) * 4);
+        if (p.use_grid) b += up(static_cast<size_t>(p.pq_cell_count) * 4) + up(static_cast<size_t>(p.pq_list_count) * 2 + 4);
+    } else if (p.accel == 1) {
+        b += up(static_cast<size_t>(p.oct_nodes) * sizeof(RmOctNode)) + up(static_cast<size_t>(p.oct_prim_count) * 4);
+    }
     b += up(static_cast<size_t>(p.n_prims) * sizeof(RmSphere)) + up(static_cast<size_t>(p.n_prims) * 8);
     return b + 16;
 }
@@ -523,16 +628,24 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
     const int rows = p.y_end - p.y_start;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
-    const int tw = p.tile_w, th = 64 / tw;
+    if (!p.tile_counters) return hipErrorInvalidValue;
+    const int tw = p.tile_w, th = 256 / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
-    const int tiles_y = (rows + 4 * th - 1) / (4 * th);
-    const unsigned blocks = 8u * static_cast<unsigned>(tiles_x) * static_cast<unsigned>((tiles_y + 7) / 8);
+    const int tiles_y = (rows + th - 1) / th;
+    const unsigned needed = static_cast<unsigned>((static_cast<long long>(tiles_x) * tiles_y + 3) / 4);  // 4 waves each
+    const unsigned resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) *
+                              static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
+    const unsigned blocks = needed < resident ? (needed ? needed : 1u) : resident;
     if (p.list_cap < 1) p.list_cap = 1;
+    if (p.refill_threshold < 1) p.refill_threshold = 1;
+    if (p.refill_threshold > 64) p.refill_threshold = 64;
     const size_t list_bytes = p.accel == 2 ? static_cast<size_t>(4) * p.list_cap * 128 : 0;
     const size_t scene_bytes = scene_lds_bytes(p);
     // stage the scene in LDS when it leaves room for >= 2 workgroups per CU (160 KB LDS)
     const bool lds = p.nodes_in_lds != 0 && scene_bytes + list_bytes + 16 <= 64 * 1024;
     const size_t shmem = (lds ? scene_bytes : 0) + list_bytes + 16;
+    hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
     const dim3 grid(blocks), block(256);
 #define RM_V2(A, L) hipLaunchKernelGGL((render_kernel_v2<A, L>), grid, block, shmem, stream, p)
     if (p.accel == 2) { if (lds) RM_V2(2, true); else RM_V2(2, false); }

@@ -173,6 +173,63 @@ struct BvhBuilder {
     }
 };
 
+// ---- point-query grid over the BVH leaves -------------------------------------------------
+//
+// Not a reference structure: an index over the leaves the reference's recursive descent
+// (bvh.ts:101-121) would reach.  Leaf boxes are unions of the padded primitive boxes and
+// every ancestor box is the exact f32 min/max of its leaves' boxes, so "p lies in leaf box L"
+// already implies "p lies in every ancestor of L": the set the descent returns is exactly
+// {leaves whose box contains p}.  The grid lists, per cell, every leaf whose box overlaps the
+// cell grown by 1 % of a cell (the device computes the cell index in binary32, error ~1e-5
+// cell), and the device re-tests each listed leaf box with the reference's inclusive f32
+// compares, so the result set is identical.
+void build_point_query_grid(HostScene &s) {
+    const int leaves = s.bvh_leaves;
+    if (s.bvh.empty() || leaves == 0) return;
+    int g = static_cast<int>(std::ceil(std::cbrt(static_cast<double>(leaves)) * 3.0));
+    g = std::max(2, std::min(g, 32));
+    size_t cells = 1;
+    for (int k = 0; k < 3; ++k) {
+        const double ext = double(s.root_max[k]) - double(s.root_min[k]);
+        s.pq_dim[k] = ext > 0 ? g : 1;
+        s.pq_origin[k] = s.root_min[k];
+        s.pq_inv[k] = ext > 0 ? static_cast<float>(s.pq_dim[k] / ext) : 0.0f;
+        cells *= static_cast<size_t>(s.pq_dim[k]);
+    }
+    std::vector<std::vector<uint16_t>> per_cell(cells);
+    bool ok = s.bvh.size() < 65536;
+    for (size_t i = 0; ok && i < s.bvh.size(); ++i) {
+        const RmBvhNode &nd = s.bvh[i];
+        if (nd.leaf < 0 || (nd.leaf & 0xFF) == 0) continue;
+        int c0[3], c1[3];
+        for (int k = 0; k < 3; ++k) {
+            const double a = (double(nd.lo[k]) - double(s.pq_origin[k])) * double(s.pq_inv[k]) - 0.01;
+            const double b = (double(nd.hi[k]) - double(s.pq_origin[k])) * double(s.pq_inv[k]) + 0.01;
+            c0[k] = std::max(0, std::min(s.pq_dim[k] - 1, static_cast<int>(std::floor(a))));
+            c1[k] = std::max(0, std::min(s.pq_dim[k] - 1, static_cast<int>(std::floor(b))));
+        }
+        for (int z = c0[2]; z <= c1[2]; ++z)
+            for (int y = c0[1]; y <= c1[1]; ++y)
+                for (int x = c0[0]; x <= c1[0]; ++x)
+                    per_cell[(static_cast<size_t>(z) * s.pq_dim[1] + y) * s.pq_dim[0] + x].push_back(
+                        static_cast<uint16_t>(i));
+    }
+    if (!ok) {  // node ids do not fit 16 bits: no grid, the device walks the tree
+        s.pq_dim[0] = s.pq_dim[1] = s.pq_dim[2] = 0;
+        return;
+    }
+    s.pq_cells.assign(cells, 0);
+    for (size_t c = 0; c < cells; ++c) {
+        const size_t n = per_cell[c].size();
+        if (n >= 255 || s.pq_list.size() + n >= (1u << 24)) {
+            s.pq_cells[c] = 255;  // too crowded: walk the tree for points of this cell
+            continue;
+        }
+        s.pq_cells[c] = static_cast<uint32_t>(s.pq_list.size() << 8) | static_cast<uint32_t>(n);
+        s.pq_list.insert(s.pq_list.end(), per_cell[c].begin(), per_cell[c].end());
+    }
+}
+
 // ---- Octree (octree.ts:36-191) ----------------------------------------------------------
 
 struct OctBuilder {
@@ -187,6 +244,8 @@ struct OctBuilder {
         node.prim_count = 0;
         node.is_empty = 1;
         node.min_distance = 0.0;
+        node.center[0] = node.center[1] = node.center[2] = 0.0f;
+        node.pad = 0;
         const int n = static_cast<int>(ids.size());
         if (depth >= 6 || n <= 4) {  // octree.ts:60
             s.oct[me].prim_first = static_cast<int>(s.oct_prims.size());
@@ -210,6 +269,7 @@ struct OctBuilder {
         const int first = static_cast<int>(s.oct.size());
         s.oct.resize(s.oct.size() + 8);
         s.oct[me].first_child = first;
+        std::memcpy(s.oct[me].center, c, sizeof c);
         for (int i = 0; i < 8; ++i) {
             if (!share[i].empty()) fill(first + i, share[i], kid[i], depth + 1);
             else fill(first + i, std::vector<int32_t>(), kid[i], 7);  // empty leaf, octree.ts:110-114
@@ -365,6 +425,7 @@ bool build_scene(HostScene &s, const float *centers, const double *radii, int n,
         if (!b.ok) return false;
         std::memcpy(s.root_min, root.lo, sizeof root.lo);
         std::memcpy(s.root_max, root.hi, sizeof root.hi);
+        build_point_query_grid(s);
     } else if (s.accel == 1) {
         Box root;  // scene.ts:81-85
         for (int k = 0; k < 3; ++k) {

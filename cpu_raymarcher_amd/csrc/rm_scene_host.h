@@ -21,6 +21,13 @@ struct HostScene {
     std::vector<RmBvhNode> bvh;
     std::vector<int32_t> bvh_prims;
     int bvh_leaves = 0, bvh_depth = 0;
+    // Uniform grid over the BVH root box that accelerates BVH.getPrimitivesAt (bvh.ts:95-121):
+    // cell -> leaves whose box may contain a point of that cell (conservative), so the device
+    // tests only those leaf boxes.  pq_cells[c] = (offset << 8) | count, count 255 = "walk the tree".
+    int pq_dim[3] = {0, 0, 0};
+    float pq_origin[3] = {0, 0, 0}, pq_inv[3] = {0, 0, 0};
+    std::vector<uint32_t> pq_cells;
+    std::vector<uint16_t> pq_list;
     std::vector<RmOctNode> oct;
     std::vector<int32_t> oct_prims;
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;

@@ -36,6 +36,8 @@ struct RmOctNode {
     double min_distance;  // octree.ts:149-191 (0 unless isEmpty)
     int32_t prim_count;
     int32_t is_empty;
+    float center[3];      // f32 split point (boundingBox.ts:108-114) = children[0].hi; internal nodes
+    int32_t pad;
 };
 
 struct RmSphere {
@@ -54,6 +56,7 @@ struct RmRenderParams {
     float rot[9];     // mat3.fromMat4(camera rotation), column-major
     float origin[3];  // camera position
     float light[3];   // normalize(f32(1,-1,1.5)) as phongModel.ts:15-16 computes it
+    double rot_d[9], origin_d[3], light_d[3];  // the same binary32 values widened on the host (exact)
     int32_t n_prims;
     int32_t accel;    // rm_accel
     int32_t shader;   // rm_shader, used when rgba != nullptr
@@ -67,7 +70,19 @@ struct RmRenderParams {
     int32_t coop;          // v2: wave-cooperative N-primitive fallback
     int32_t bvh_prim_count;
     int32_t oct_prim_count;
-    int32_t reserved0;
+    int32_t blocks_per_cu;  // v2: persistent workgroups per CU
+    int32_t num_cus;
+    int32_t pq_dim[3];      // BVH point-query grid (rm_scene_host.cpp), 0 = absent
+    int32_t pq_cell_count;
+    int32_t pq_list_count;
+    int32_t use_grid;
+    float pq_origin[3];
+    float pq_inv[3];
+    int32_t refill_threshold;  // v2: idle lanes that trigger a ballot/prefix refill (64 = whole wave)
+    int32_t hw_xcd;            // v2: read the XCD id from HW_REG_XCC_ID instead of blockIdx % 8
+    unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch
+    const uint32_t *pq_cells;
+    const uint16_t *pq_list;
     const RmSphere *spheres;
     const double *radii;
     const RmBvhNode *bvh;

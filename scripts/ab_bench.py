@@ -44,7 +44,8 @@ def main():
     rg = torch.zeros(4 * W * H, dtype=torch.uint8, device=dev)
     tr = R.SphereTracer()
     ref = None
-    defaults = {k: ctx.get_option(k) for k in ("kernel", "tile_w", "filter", "nodes_in_lds", "list_cap", "coop")}
+    defaults = {k: ctx.get_option(k) for k in ("kernel", "tile_w", "filter", "nodes_in_lds", "list_cap", "coop", "grid",
+                                               "blocks_per_cu", "refill", "hw_xcd")}
     for v in variants:
         for k, val in defaults.items():
             ctx.set_option(k, val)

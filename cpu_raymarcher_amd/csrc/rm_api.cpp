@@ -64,6 +64,7 @@ struct rm_ctx {
     int64_t opt_blocks_per_cu = 3;
     int64_t opt_refill = 64;
     int64_t opt_hw_xcd = 1;
+    int64_t opt_item_px = 64;
     unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
     unsigned int counter_slot = 0;
     int num_cus = 256;
@@ -217,6 +218,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.num_cus = ctx->num_cus;
     p.refill_threshold = static_cast<int32_t>(ctx->opt_refill);
     p.hw_xcd = static_cast<int32_t>(ctx->opt_hw_xcd);
+    p.item_px = static_cast<int32_t>(ctx->opt_item_px);
     p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 64) : nullptr;
     for (int k = 0; k < 3; ++k) {
         p.pq_dim[k] = ctx->host.pq_dim[k];
@@ -609,6 +611,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_refill = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "item_px")) {
+        if (value != 64 && value != 128 && value != 256) return fail(ctx, RM_E_INVALID, "item_px must be 64, 128 or 256");
+        ctx->opt_item_px = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "hw_xcd")) {
         ctx->opt_hw_xcd = value ? 1 : 0;
         return RM_OK;
@@ -636,6 +643,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "grid")) *value = ctx->opt_grid;
     else if (!std::strcmp(key, "refill")) *value = ctx->opt_refill;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
+    else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;
     else return RM_E_INVALID;
     return RM_OK;

@@ -116,6 +116,39 @@ __device__ __forceinline__ double min_dist(double candidate, double closest) {
     return candidate < closest ? candidate : closest;
 }
 
+// min(closest, min over ids[0..n) -- or 0..n-1 when ids is null -- of Sphere.sdf), the loop of
+// scene.ts:155-158,175-178,183-187.  With `filter` a sphere is evaluated exactly only when its
+// conservative binary32 lower bound does not exceed an upper bound of the best value so far;
+// a skipped sphere has exact > best >= result, and min() does not depend on order, so the
+// value is bit-identical to the plain loop.  FAST selects the shared-reciprocal hypot.
+template <bool FAST>
+__device__ __forceinline__ double prims_min(const RmSphere *spheres, const double *radii, const int32_t *ids, int n,
+                                            const Vec3f &p, double closest, bool filter) {
+    if (!filter || n < 2) {
+        for (int k = 0; k < n; ++k) {
+            const int id = ids ? ids[k] : k;
+            const double e = FAST ? sphere_sdf_fast(spheres[id], radii[id], p) : sphere_sdf(spheres[id], radii[id], p);
+            closest = min_dist(e, closest);
+        }
+        return closest;
+    }
+    float ub = __double2float_ru(closest);
+    for (int k = 0; k < n; ++k) {
+        const int id = ids ? ids[k] : k;
+        const RmSphere s = spheres[id];
+        float err;
+        const float a = sphere_sdf_estimate(s, p, err);
+        if (a - err <= ub) {
+            const double e = FAST ? sphere_sdf_fast(s, radii[id], p) : sphere_sdf(s, radii[id], p);
+            if (e < closest) {
+                closest = e;
+                ub = __double2float_ru(e);
+            }
+        }
+    }
+    return closest;
+}
+
 // BoundingBox.contains (boundingBox.ts:15-21)
 __device__ __forceinline__ bool box_contains(const float lo[3], const float hi[3], const Vec3f &p) {
     return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];

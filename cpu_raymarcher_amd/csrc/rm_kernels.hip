@@ -30,7 +30,7 @@ using namespace rmd;
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
 __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
-    for (int i = 0; i < P.n_prims; ++i) closest = min_dist(sphere_sdf(P.spheres[i], P.radii[i], p), closest);
+    closest = prims_min<false>(P.spheres, P.radii, nullptr, P.n_prims, p, closest, P.filter != 0);
     count += static_cast<uint32_t>(P.n_prims);
     return closest;
 }
@@ -53,10 +53,7 @@ __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t
             continue;
         }
         const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
-        for (int k = 0; k < cnt; ++k) {
-            const int id = P.bvh_prims[first + k];
-            closest = min_dist(sphere_sdf(P.spheres[id], P.radii[id], p), closest);
-        }
+        closest = prims_min<false>(P.spheres, P.radii, P.bvh_prims + first, cnt, p, closest, P.filter != 0);
         found += static_cast<uint32_t>(cnt);
         i = node.skip;
     }
@@ -75,7 +72,7 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
     for (;;) {
         const int first = nodes[i].first_child;
         if (first < 0) return i;
-        const float cx = nodes[first].hi[0], cy = nodes[first].hi[1], cz = nodes[first].hi[2];
+        const float cx = nodes[i].center[0], cy = nodes[i].center[1], cz = nodes[i].center[2];
         i = first + (p.x > cx ? 1 : 0) + (p.y > cy ? 2 : 0) + (p.z > cz ? 4 : 0);
     }
 }
@@ -86,10 +83,8 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
     const RmOctNode nd = P.oct[node];
     double closest = RM_MAX_DIST;
     if (nd.prim_count > 0) {
-        for (int k = 0; k < nd.prim_count; ++k) {
-            const int id = P.oct_prims[nd.prim_first + k];
-            closest = min_dist(sphere_sdf(P.spheres[id], P.radii[id], p), closest);
-        }
+        closest = prims_min<false>(P.spheres, P.radii, P.oct_prims + nd.prim_first, nd.prim_count, p, closest,
+                                   P.filter != 0);
         count += static_cast<uint32_t>(nd.prim_count);
     } else if (nd.is_empty) {
         closest = min_dist(nd.min_distance * 0.99, closest);  // Math.min(closest, minDistance * safety)

@@ -354,12 +354,13 @@ __device__ __forceinline__ const T *stage(unsigned char *smem, size_t &off, cons
     return dst;
 }
 
-// Wave-granular work queue: a work item is one 256-pixel tile (tile_w wide, 256 / tile_w tall).
+// Wave-granular work queue: a work item is one tile of item_px (64, 128 or 256) pixels, tile_w
+// wide and item_px / tile_w tall.
 // XCD x owns the tile rows r with r % 8 == x, so the partial-line stores of horizontally
 // adjacent tiles meet in one L2; a wave whose XCD queue is empty steals from the others.
 struct TileQueue {
     unsigned int *counters;  // one per XCD, zeroed by the host before the launch
-    int tiles_x, tiles_y, tile_w, tile_h;
+    int tiles_x, tiles_y, tile_w, tile_h, item_px;
 };
 
 // next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     TileQueue Q;
     Q.counters = P.tile_counters;
     Q.tile_w = P.tile_w;
-    Q.tile_h = 256 / P.tile_w;
+    Q.item_px = P.item_px;
+    Q.tile_h = P.item_px / P.tile_w;
     const int rows = P.y_end - P.y_start;
     Q.tiles_x = (P.width + Q.tile_w - 1) / Q.tile_w;
     Q.tiles_y = (rows + Q.tile_h - 1) / Q.tile_h;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     const int refill_at = P.refill_threshold;  // refill as soon as this many lanes are idle
 
     // ---- wave state: the tile being consumed ------------------------------------------------
-    int tile_col = 0, tile_row = 0, qpos = 256;  // qpos: next pixel of the current tile (256 = used up)
+    int tile_col = 0, tile_row = 0, qpos = Q.item_px;  // qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
 
     // ---- lane state ------------------------------------------------------------------------
@@ -471,12 +473,12 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
                 store_pixel(P, static_cast<size_t>(prow) * P.width + px, depth, nx, ny, nz, count, iters);
                 have_pixel = false;
             }
-            if (!no_more && qpos >= 256) {
+            if (!no_more && qpos >= Q.item_px) {
                 if (pull_tile(Q, home, tile_col, tile_row, lane)) qpos = 0;
                 else no_more = true;
             }
             if (!no_more) {
-                const int remaining = 256 - qpos;
+                const int remaining = Q.item_px - qpos;
                 const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(idle >> 32),
                                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(idle), 0u));
                 const bool take = phase == PH_DONE && rank < remaining;
@@ -629,7 +631,9 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     const int rows = p.y_end - p.y_start;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (!p.tile_counters) return hipErrorInvalidValue;
-    const int tw = p.tile_w, th = 256 / tw;
+    if (p.item_px != 64 && p.item_px != 128 && p.item_px != 256) p.item_px = 64;
+    if (p.item_px < p.tile_w) p.item_px = p.tile_w;
+    const int tw = p.tile_w, th = p.item_px / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + th - 1) / th;
     const unsigned needed = static_cast<unsigned>((static_cast<long long>(tiles_x) * tiles_y + 3) / 4);  // 4 waves each

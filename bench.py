@@ -156,28 +156,28 @@ def main():
             else:
                 render_rows(a, b, local, packed)
 
-        shr = D.ShardedFrameRenderer(layout, rank, world, timed_render_rows, u8, dist)
-        # rank 0 reassembly: one indexed row-gather per section
+        render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank)
+
+        def timed_render_all(packed):
+            if timed_flag[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                render_all(packed)
+                e1.record()
+                ev_pairs.append((e0, e1))
+            else:
+                render_all(packed)
+
+        shr = D.ShardedFrameRenderer(layout, rank, world, timed_render_rows, u8, dist,
+                                     render_all=timed_render_all if render_all else None)
+        # rank 0 reassembly: one indexed row-gather per section (D.GpuFrameAssembler)
+        asm = None
         if rank == 0:
-            frame = {s: u8(D.SECTION_BYTES[s] * W * H) for s in layout.sections}
-            rank_of_row = torch.empty(H, dtype=torch.int64)
-            local_of_row = torch.empty(H, dtype=torch.int64)
-            for r in range(world):
-                loc = 0
-                for (a, b) in layout.rows(r):
-                    rank_of_row[a:b] = r
-                    local_of_row[a:b] = torch.arange(loc, loc + b - a)
-                    loc += b - a
-            rank_of_row, local_of_row = rank_of_row.to(dev), local_of_row.to(dev)
-            recv2d = [torch.zeros(world, layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(shr.nbuf)]
-            shr.recv = [list(t.unbind(0)) for t in recv2d]
+            asm = D.GpuFrameAssembler(layout, dev, shr.nbuf)
+            shr.recv = asm.gather_lists()
 
         def assemble(slot):
-            for s in layout.sections:
-                bpp = D.SECTION_BYTES[s]
-                off = layout.offsets[s]
-                src = recv2d[slot][:, off:off + layout.cap * W * bpp].unflatten(1, (layout.cap, W * bpp))
-                frame[s].view(H, W * bpp).copy_(src[rank_of_row, local_of_row])
+            frame = asm.assemble(slot)
             ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), acc)
 
         pending = []
@@ -226,8 +226,21 @@ def main():
         px_per_launch = W * H
     else:
         rows_mine = layout.rows(rank)
-        px_per_launch = W * sum(b - a for a, b in rows_mine) / max(1, len(rows_mine))
+        launches = 1 if args.partition == "interleaved" else max(1, len(rows_mine))
+        px_per_launch = W * sum(b - a for a, b in rows_mine) / launches
     achieved = ALG_BYTES_PER_PIXEL * px_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+    # the per-launch figure measured with rocprofv3 for this workload is taken from the committed
+    # profile (profiles/r01/traffic.json, which names its source), at N = 1 only.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
+            tj = json.load(f)
+        if world == 1 and args.workload in tj and not args.opt:
+            traffic = tj[args.workload]["bytes"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
 
     if rank == 0:
         d = ctx.decode_acc(acc)
@@ -247,7 +260,10 @@ def main():
             "max_sdf_calls": d["max_sdf"], "min_sdf_calls": d["min_sdf"],
             "sphere_evals_per_s": d["total_sdf"] * fps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "render_kernel",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/traffic.json"
+                         if traffic else None,
+                         "kernel": "render_kernel_v2<2,true>" if args.workload == "C3" else "render kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_PIXEL * px_per_launch,
                          "note": "FP64-VALU/divergence bound, not HBM bound: 12 B/pixel out, ~1e3 FP64 ops/pixel "
                                  "(DESIGN.md)"},

@@ -74,6 +74,9 @@ SIGNATURES = {
     "rm_scene_distance": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP]),
     "rm_render_tile": (C.c_int, [_VP, C.POINTER(rm_job), _VP, _VP, _VP, _VP]),
     "rm_render_tile_device": (C.c_int, [_VP, C.POINTER(rm_job), C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rm_render_stripes_device": (C.c_int, [_VP, C.POINTER(rm_job), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rm_stripe_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_shade": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP]),
     "rm_shade_device": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rm_reduce_counters": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics)]),

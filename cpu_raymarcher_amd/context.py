@@ -107,6 +107,12 @@ class Context:
             rows = max(0, job.y_end - job.y_start)
             self.shade(shader, job.width, rows, depth, normal, sdf, iters, rgba)
 
+    def render_stripes(self, job, stripe_rows, n_parts, part, depth, normal, sdf, iters, rgba=None, shader=0):
+        """One launch for every stripe of `part` (rm_render_stripes_device); device buffers only."""
+        N.check(self._h, N.lib().rm_render_stripes_device(
+            self._h, C.byref(job), int(shader), int(stripe_rows), int(n_parts), int(part), _ptr(depth), _ptr(normal),
+            _ptr(sdf), _ptr(iters), _ptr(rgba), _current_stream_ptr()))
+
     def shade(self, shader, width, height, depth, normal, sdf, iters, rgba):
         if _is_torch(rgba):
             N.check(self._h, N.lib().rm_shade_device(self._h, int(shader), width, height, _ptr(depth),

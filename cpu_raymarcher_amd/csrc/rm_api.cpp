@@ -194,6 +194,10 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.height = job->height;
     p.y_start = job->y_start;
     p.y_end = job->y_end;
+    p.local_rows = job->y_end > job->y_start ? job->y_end - job->y_start : 0;
+    p.stripe_rows = 0;
+    p.n_parts = 1;
+    p.part = 0;
     rmh::camera_from_angles(job->camera_pitch, job->camera_yaw, p.rot, p.origin);
     std::memcpy(p.light, ctx->light, sizeof p.light);
     for (int k = 0; k < 9; ++k) p.rot_d[k] = p.rot[k];
@@ -370,6 +374,43 @@ int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader, void *
     RmRenderParams p;
     int rc = fill_params(ctx, job, p);
     if (rc) return rc;
+    p.shader = norm_shader(shader);
+    p.depth = static_cast<uint8_t *>(d_depth);
+    p.normal = static_cast<uint8_t *>(d_normal);
+    p.sdf = static_cast<uint16_t *>(d_sdf);
+    p.iters = static_cast<uint16_t *>(d_iters);
+    p.rgba = static_cast<uint8_t *>(d_rgba);
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, rm_launch_render(p, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_stripe_rows(int32_t y_start, int32_t y_end, int32_t stripe_rows, int32_t n_parts, int32_t part) {
+    if (stripe_rows <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return RM_E_INVALID;
+    const int64_t rows = y_end > y_start ? static_cast<int64_t>(y_end) - y_start : 0;
+    int64_t mine = 0;
+    for (int64_t s = part; s * stripe_rows < rows; s += n_parts) {
+        const int64_t a = s * stripe_rows, b = a + stripe_rows;
+        mine += (b < rows ? b : rows) - a;
+    }
+    return static_cast<int>(mine);
+}
+
+int rm_render_stripes_device(rm_ctx *ctx, const rm_job *job, int32_t shader, int32_t stripe_rows, int32_t n_parts,
+                             int32_t part, void *d_depth, void *d_normal, void *d_sdf, void *d_iters, void *d_rgba,
+                             void *stream) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context: there is no CPU render path");
+    if (!job) return fail(ctx, RM_E_INVALID, "null job");
+    const int mine = rm_stripe_rows(job->y_start, job->y_end, stripe_rows, n_parts, part);
+    if (mine < 0) return fail(ctx, RM_E_INVALID, "bad stripe partition");
+    RmRenderParams p;
+    int rc = fill_params(ctx, job, p);
+    if (rc) return rc;
+    p.local_rows = mine;
+    p.stripe_rows = stripe_rows;
+    p.n_parts = n_parts;
+    p.part = part;
     p.shader = norm_shader(shader);
     p.depth = static_cast<uint8_t *>(d_depth);
     p.normal = static_cast<uint8_t *>(d_normal);

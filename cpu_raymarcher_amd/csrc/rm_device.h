@@ -276,6 +276,15 @@ __device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, do
 
 // ------------------------------------------------------------------ ray generation / stores
 
+// packed (launch-local) row -> frame row y.  Without striping the tile is the contiguous range
+// [y_start, y_end) of the Job (raymarchWorker.ts:14-15); with striping (multi-GPU sharding) the
+// launch owns every n_parts-th stripe of stripe_rows rows.
+__device__ __forceinline__ int row_to_y(const RmRenderParams &P, int r) {
+    if (P.stripe_rows <= 0) return P.y_start + r;
+    const int s = r / P.stripe_rows;
+    return P.y_start + (s * P.n_parts + P.part) * P.stripe_rows + (r - s * P.stripe_rows);
+}
+
 // raymarcher.ts:73,83-88: u, v from full-frame W, H; fromValues, transformMat3, normalize
 __device__ __forceinline__ Ray make_ray(const RmRenderParams &P, int x, int y) {
     const double v = (static_cast<double>(y) / static_cast<double>(P.height) - 0.5) * 2.0;

@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
     const int x = bx * tw + (lane % tw);
     const int row = by * (4 * th) + wave * th + (lane / tw);  // tile-local row
-    const int rows = P.y_end - P.y_start;
+    const int rows = P.local_rows;
     if (x >= P.width || row >= rows) return;
-    const int y = P.y_start + row;
+    const int y = row_to_y(P, row);
     const size_t idx = static_cast<size_t>(row) * P.width + x;
 
     // raymarcher.ts:73,83-88
@@ -295,8 +295,31 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const 
                                                      RmDiagDevice *acc) {
     unsigned long long s = 0, it = 0;
     unsigned int mx = 0, mn = 0xFFFFFFFFu;
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    const int64_t nthreads = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    int64_t done = 0;
+    // 16-byte loads (8 counters per lane per load) when both streams are 16-byte aligned
+    if (((reinterpret_cast<uintptr_t>(sdf) | reinterpret_cast<uintptr_t>(iters)) & 15) == 0) {
+        const int64_t nvec = n / 8;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(sdf);
+        const uint4 *i4 = reinterpret_cast<const uint4 *>(iters);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            const uint4 a = s4[v], b = i4[v];
+            const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned int lo = aw[k] & 0xFFFFu, hi = aw[k] >> 16;
+                s += lo + hi;
+                mx = lo > mx ? lo : mx;
+                mx = hi > mx ? hi : mx;
+                mn = lo < mn ? lo : mn;
+                mn = hi < mn ? hi : mn;
+                it += (bw[k] & 0xFFFFu) + (bw[k] >> 16);
+            }
+        }
+        done = nvec * 8;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
         const unsigned int c = sdf[i];
         s += c;
         it += iters[i];
@@ -393,7 +416,7 @@ hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long lo
 // ---------------------------------------------------------------------- launchers
 
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
-    const int rows = p.y_end - p.y_start;
+    const int rows = p.local_rows;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (p.variant == 2) return rm_launch_render_v2(p, stream);
     const int tw = p.tile_w, th = 64 / tw;
@@ -424,8 +447,9 @@ hipError_t rm_launch_reduce_init(RmDiagDevice *acc, hipStream_t stream) {
 hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t n, RmDiagDevice *acc,
                             hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sdf, iters, n, acc);
     return hipGetLastError();
 }

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     Q.tile_w = P.tile_w;
     Q.item_px = P.item_px;
     Q.tile_h = P.item_px / P.tile_w;
-    const int rows = P.y_end - P.y_start;
+    const int rows = P.local_rows;
     Q.tiles_x = (P.width + Q.tile_w - 1) / Q.tile_w;
     Q.tiles_y = (rows + Q.tile_h - 1) / Q.tile_h;
     // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
                     prow = tile_row * Q.tile_h + sub * (64 / Q.tile_w) + (l / Q.tile_w);
                     if (px < P.width && prow < rows) {
                         have_pixel = true;
-                        ray = make_ray(P, px, P.y_start + prow);
+                        ray = make_ray(P, px, row_to_y(P, prow));
                         count = 0;
                         iters = 0;
                         loopi = 0;
@@ -628,7 +628,7 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
 
 hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
-    const int rows = p.y_end - p.y_start;
+    const int rows = p.local_rows;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (!p.tile_counters) return hipErrorInvalidValue;
     if (p.item_px != 64 && p.item_px != 128 && p.item_px != 256) p.item_px = 64;

@@ -81,6 +81,9 @@ struct RmRenderParams {
     int32_t refill_threshold;  // v2: idle lanes that trigger a ballot/prefix refill (64 = whole wave)
     int32_t hw_xcd;            // v2: read the XCD id from HW_REG_XCC_ID instead of blockIdx % 8
     int32_t item_px;           // v2: pixels per work item (64, 128, 256)
+    int32_t local_rows;        // packed rows this launch renders (= y_end - y_start without striping)
+    int32_t stripe_rows;       // > 0: rows are dealt in stripes of this many rows, round-robin over n_parts;
+    int32_t n_parts, part;     //      this launch renders the stripes of `part`, packed in increasing y
     int32_t reserved1;
     unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch
     const uint32_t *pq_cells;

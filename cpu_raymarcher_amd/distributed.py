@@ -85,9 +85,10 @@ class ShardedFrameRenderer:
     sections of `packed` starting at tile-local row `local_row` (on the GPU: one
     rm_render_tile_device launch per range; the CPU gloo test injects the oracle)."""
 
-    def __init__(self, layout, rank, world, render_rows, new_buffer, dist=None, double_buffer=True):
+    def __init__(self, layout, rank, world, render_rows, new_buffer, dist=None, double_buffer=True, render_all=None):
         self.layout, self.rank, self.world = layout, rank, world
         self.render_rows = render_rows
+        self.render_all = render_all  # optional: one call that fills every owned row of `packed`
         self.dist = dist
         self.nbuf = 2 if double_buffer else 1
         self.send = [new_buffer(layout.nbytes) for _ in range(self.nbuf)]
@@ -97,6 +98,9 @@ class ShardedFrameRenderer:
         self.step = 0
 
     def render_local(self, slot):
+        if self.render_all is not None:
+            self.render_all(self.send[slot])
+            return
         local = 0
         for (a, b) in self.layout.rows(self.rank):
             self.render_rows(a, b, local, self.send[slot])
@@ -153,3 +157,59 @@ def gpu_render_rows(ctx, scene, width, height, shader, layout):
         job = _job(scene, width, height, 0.0, y0, y1, "sphere-tracer")
         ctx.render_tile(job, sec("depth"), sec("normal"), sec("sdf"), sec("iters"), rgba=sec("rgba"), shader=sh)
     return render_rows
+
+
+def gpu_render_all(ctx, scene, width, height, shader, layout, rank):
+    """render_all callback for the GPU and the interleaved partition: ONE rm_render_stripes_device
+    launch writes every stripe of this rank into the packed buffer."""
+    from . import _native as N
+    from .host import _job
+    if layout.mode != "interleaved":
+        return None
+    sh = N.lib().rm_shader_from_string(str(shader).encode())
+    want = set(layout.sections)
+
+    def render_all(packed):
+        def sec(name):
+            return layout.section(packed, name) if name in want else None
+        job = _job(scene, width, height, 0.0, 0, height, "sphere-tracer")
+        ctx.render_stripes(job, layout.stripe, layout.world, rank, sec("depth"), sec("normal"), sec("sdf"),
+                           sec("iters"), rgba=sec("rgba"), shader=sh)
+    return render_all
+
+
+class GpuFrameAssembler:
+    """Rank 0's reassembly on the device: the gather lands in one [world, nbytes] tensor per
+    slot; one indexed row-gather per section writes the row-major frame (3 small kernels per
+    frame instead of one copy per stripe)."""
+
+    def __init__(self, layout, device, nbuf=2):
+        import torch
+        self.layout, self.torch = layout, torch
+        W, H = layout.width, layout.height
+        rank_of_row = torch.empty(H, dtype=torch.int64)
+        local_of_row = torch.empty(H, dtype=torch.int64)
+        for r in range(layout.world):
+            loc = 0
+            for (a, b) in layout.rows(r):
+                rank_of_row[a:b] = r
+                local_of_row[a:b] = torch.arange(loc, loc + b - a)
+                loc += b - a
+        self.rank_of_row, self.local_of_row = rank_of_row.to(device), local_of_row.to(device)
+        self.recv2d = [torch.zeros(layout.world, layout.nbytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.frame = {s: torch.zeros(SECTION_BYTES[s] * W * H, dtype=torch.uint8, device=device)
+                      for s in layout.sections}
+
+    def gather_lists(self):
+        """Per slot, the list of per-rank views torch.distributed.gather writes into."""
+        return [list(t.unbind(0)) for t in self.recv2d]
+
+    def assemble(self, slot):
+        L = self.layout
+        W, H = L.width, L.height
+        for s in L.sections:
+            bpp = SECTION_BYTES[s]
+            off = L.offsets[s]
+            src = self.recv2d[slot][:, off:off + L.cap * W * bpp].unflatten(1, (L.cap, W * bpp))
+            self.frame[s].view(H, W * bpp).copy_(src[self.rank_of_row, self.local_of_row])
+        return self.frame

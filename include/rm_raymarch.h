@@ -169,6 +169,17 @@ RM_API int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader,
                                  void *d_normal, void *d_sdf, void *d_iters, void *d_rgba,
                                  void *stream);
 
+/* Multi-GPU sharding of one Job (replaces the contiguous ceil(H/N) split of main.ts:444-449
+ * by a load-balanced one): the rows [y_start, y_end) are cut into stripes of `stripe_rows`
+ * rows dealt round-robin over `n_parts`; this call renders, in ONE launch, the stripes of
+ * `part`, packed in increasing y (rm_stripe_rows rows of `width` pixels).  Pixels are pure
+ * functions of (x, y, W, H, camera, scene) (raymarcher.ts:72-76,83), so any row subset is exact. */
+RM_API int rm_render_stripes_device(rm_ctx *ctx, const rm_job *job, int32_t shader, int32_t stripe_rows,
+                                    int32_t n_parts, int32_t part, void *d_depth, void *d_normal,
+                                    void *d_sdf, void *d_iters, void *d_rgba, void *stream);
+/* number of rows part `part` owns (>= 0), or RM_E_INVALID */
+RM_API int rm_stripe_rows(int32_t y_start, int32_t y_end, int32_t stripe_rows, int32_t n_parts, int32_t part);
+
 /* Replaces ShadingModel.shade(shaded, depth, normal, sdfEval, iters, width, height)
  * (shadingModel.ts:8-17 and the four models), host buffers. */
 RM_API int rm_shade(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height,

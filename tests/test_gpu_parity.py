@@ -222,6 +222,59 @@ def test_fused_render_and_shade_on_device_buffers(rm, gpu_ctx, oracle):
     assert torch.equal(rg, rg2)
 
 
+@pytest.mark.parametrize("world,stripe,accel", [(2, 16, "BVH"), (3, 4, "Octree"), (8, 16, "BVH"), (8, 7, "None")])
+def test_striped_sharding_reassembles_the_frame(rm, gpu_ctx, oracle, world, stripe, accel):
+    """The multi-GPU path on one GPU: every 'rank' renders its interleaved stripes with ONE
+    rm_render_stripes_device launch into the packed buffer the gather would move; rank 0's
+    reassembly must reproduce the full frame (which must equal the oracle)."""
+    import torch
+    from cpu_raymarcher_amd import distributed as D
+    W, H = 200, 131  # H is not a multiple of stripe * world
+    dev = torch.device("cuda:0")
+    sc = rm.Scene(accel, ctx=gpu_ctx)
+    sc.loadPreset(3)
+    sc.camera.setAngles(0.15, -0.4)
+    sections = ("rgba", "sdf", "iters", "depth", "normal")
+    layout = D.FrameLayout(W, H, world, sections, "interleaved", stripe)
+    packed = []
+    for rank in range(world):
+        buf = torch.zeros(layout.nbytes, dtype=torch.uint8, device=dev)
+        D.gpu_render_all(gpu_ctx, sc, W, H, "sdf-heatmap", layout, rank)(buf)
+        assert sum(b - a for a, b in layout.rows(rank)) == \
+            rm._native.lib().rm_stripe_rows(0, H, stripe, world, rank)
+        packed.append(buf)
+    torch.cuda.synchronize()
+    frame = D.new_frame(layout, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev))
+    layout.scatter_into_frame(packed, frame)
+    want = cpu_render(oracle, 3, accel, W, H, (0.15, -0.4))
+    got = (frame["depth"].cpu().numpy(), frame["normal"].cpu().numpy(),
+           frame["sdf"].cpu().numpy().view(np.uint16), frame["iters"].cpu().numpy().view(np.uint16))
+    assert_same(got, want, "striped world=%d" % world)
+    assert np.array_equal(frame["rgba"].cpu().numpy(), oracle.shade("sdf-heatmap", *want, W, H))
+    # rank 0's device-side reassembly (what bench.py runs after the gather)
+    asm = D.GpuFrameAssembler(layout, dev, 1)
+    for rank in range(world):
+        asm.recv2d[0][rank].copy_(packed[rank])
+    fr = asm.assemble(0)
+    for s in sections:
+        assert torch.equal(fr[s], frame[s]), s
+    # the per-range path (contiguous partition) gives the same bytes
+    layout_c = D.FrameLayout(W, H, world, sections, "contiguous", stripe)
+    packed_c = []
+    for rank in range(world):
+        buf = torch.zeros(layout_c.nbytes, dtype=torch.uint8, device=dev)
+        rr = D.gpu_render_rows(gpu_ctx, sc, W, H, "sdf-heatmap", layout_c)
+        local = 0
+        for (a, b) in layout_c.rows(rank):
+            rr(a, b, local, buf)
+            local += b - a
+        packed_c.append(buf)
+    frame_c = D.new_frame(layout_c, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev))
+    layout_c.scatter_into_frame(packed_c, frame_c)
+    for s in sections:
+        assert torch.equal(frame[s], frame_c[s]), s
+
+
 def test_worker_fan_out_fan_in(rm, gpu_ctx, oracle):
     # main.ts:444-468 with 4 workers on one context; H not divisible by 4
     workers = [rm.RaymarchWorker(ctx=gpu_ctx) for _ in range(4)]

@@ -333,7 +333,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const 
         mx = omx > mx ? omx : mx;
         mn = omn < mn ? omn : mn;
     }
+    // one atomic set per workgroup: the four words share a cache line, so per-wave atomics from
+    // thousands of waves serialise (measured: 0.39 ms for 8192 waves vs the ~15 us the loads take)
+    __shared__ unsigned long long sh_s[4], sh_it[4];
+    __shared__ unsigned int sh_mx[4], sh_mn[4];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
+        sh_s[w] = s;
+        sh_it[w] = it;
+        sh_mx[w] = mx;
+        sh_mn[w] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            s += sh_s[k];
+            it += sh_it[k];
+            mx = sh_mx[k] > mx ? sh_mx[k] : mx;
+            mn = sh_mn[k] < mn ? sh_mn[k] : mn;
+        }
         atomicAdd(&acc->total_sdf, s);
         atomicAdd(&acc->total_iters, it);
         atomicMax(&acc->max_sdf, mx);
@@ -448,7 +466,7 @@ hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t 
                             hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n / 8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sdf, iters, n, acc);
     return hipGetLastError();

@@ -121,8 +121,8 @@ __device__ __forceinline__ double min_dist(double candidate, double closest) {
 // conservative binary32 lower bound does not exceed an upper bound of the best value so far;
 // a skipped sphere has exact > best >= result, and min() does not depend on order, so the
 // value is bit-identical to the plain loop.  FAST selects the shared-reciprocal hypot.
-template <bool FAST>
-__device__ __forceinline__ double prims_min(const RmSphere *spheres, const double *radii, const int32_t *ids, int n,
+template <bool FAST, typename IdT = int32_t>
+__device__ __forceinline__ double prims_min(const RmSphere *spheres, const double *radii, const IdT *ids, int n,
                                             const Vec3f &p, double closest, bool filter) {
     if (!filter || n < 2) {
         for (int k = 0; k < n; ++k) {

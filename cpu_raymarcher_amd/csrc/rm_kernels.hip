@@ -30,7 +30,7 @@ using namespace rmd;
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
 __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
-    closest = prims_min<false>(P.spheres, P.radii, nullptr, P.n_prims, p, closest, P.filter != 0);
+    closest = prims_min<false>(P.spheres, P.radii, static_cast<const int32_t *>(nullptr), P.n_prims, p, closest, P.filter != 0);
     count += static_cast<uint32_t>(P.n_prims);
     return closest;
 }

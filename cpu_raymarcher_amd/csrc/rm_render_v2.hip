@@ -33,6 +33,25 @@ namespace {
 
 using namespace rmd;
 
+// Diagnostic build only (-DRM_STAMPS): per-section cycle shares of the wave loop, accumulated per
+// wave and added to P.stamps[0..7] at the end.  No stamp executes in the product build.
+#ifdef RM_STAMPS
+#define RM_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RM_T(i)                                                  \
+    {                                                            \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
+        t_acc_[i] += t_now_ - t_prev_;                           \
+        t_prev_ = t_now_;                                        \
+    }
+#define RM_TEND()                                                                      \
+    if (lane == 0 && P.stamps)                                                          \
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.stamps[i_], t_acc_[i_]);
+#else
+#define RM_T0()
+#define RM_T(i)
+#define RM_TEND()
+#endif
+
 enum Phase : int { PH_MARCH = 0, PH_N0 = 1, PH_N1 = 2, PH_N2 = 3, PH_N3 = 4, PH_DONE = 5 };
 
 struct SceneView {
@@ -44,25 +63,46 @@ struct SceneView {
     const double *radii;
     const uint32_t *pq_cells;
     const uint16_t *pq_list;
+    const uint32_t *nn_cells;
+    const uint16_t *nn_list;
     int n_prims, bvh_nodes;
 };
 
+// Wave-wide minimum of a binary32 value with DPP row operations (no LDS traffic; the
+// ds_bpermute form of __shfl_xor cost 18 LDS round trips per fallback ray).  Every lane of the
+// wave must be active.  Steps: xor 1, xor 2 inside quads, half-row mirror, row mirror (each
+// row of 16 now holds its minimum in every lane), row_bcast15 into rows 1 and 3, row_bcast31
+// into rows 2 and 3; lane 63 then holds the minimum of all 64 lanes.
 __device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float o = __shfl_xor(v, off);
-        v = o < v ? o : v;
+    int b = __float_as_int(v);
+#define RM_DPP_MIN(ctrl, rowmask)                                                              \
+    {                                                                                          \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(b, b, ctrl, rowmask, 0xF, false)); \
+        const float c = __int_as_float(b);                                                     \
+        b = __float_as_int(o < c ? o : c);                                                     \
     }
-    return v;
+    RM_DPP_MIN(0xB1, 0xF)   // quad_perm [1,0,3,2]
+    RM_DPP_MIN(0x4E, 0xF)   // quad_perm [2,3,0,1]
+    RM_DPP_MIN(0x141, 0xF)  // row_half_mirror
+    RM_DPP_MIN(0x140, 0xF)  // row_mirror
+    RM_DPP_MIN(0x142, 0xA)  // row_bcast15 -> rows 1, 3
+    RM_DPP_MIN(0x143, 0xC)  // row_bcast31 -> rows 2, 3
+#undef RM_DPP_MIN
+    return __int_as_float(__builtin_amdgcn_readlane(b, 63));
 }
 
-__device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(v, off);
-        v = o < v ? o : v;
+// minimum over the lanes in `mask` of a double each of them holds (typically one or two
+// candidate lanes): scalar loop over the set bits with v_readlane, no cross-lane network
+__device__ __forceinline__ double masked_min_f64(double v, unsigned long long mask, double init) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double best = init;
+    while (mask) {
+        const int src = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const double o = __hiloint2double(__builtin_amdgcn_readlane(hi, src), __builtin_amdgcn_readlane(lo, src));
+        best = o < best ? o : best;
     }
-    return v;
+    return best;
 }
 
 __device__ __forceinline__ float readlane_f32(float v, int src_lane) {
@@ -114,13 +154,20 @@ __device__ double coop_all_prims(const SceneView &S, const Vec3f &b, int lane) {
     }
     ub = wave_min_f32(ub);
     double best = RM_MAX_DIST;
-    for (int j = lane; j < S.n_prims; j += 64) {
-        const RmSphere s = S.spheres[j];
-        float err;
-        const float a = sphere_sdf_estimate(s, b, err);
-        if (a - err <= ub) best = min_dist(sphere_sdf_fast(s, S.radii[j], b), best);
+    for (int j0 = 0; j0 < S.n_prims; j0 += 64) {  // wave-uniform trip count
+        const int j = j0 + lane;
+        bool cand = false;
+        double e = RM_MAX_DIST;
+        if (j < S.n_prims) {
+            const RmSphere s = S.spheres[j];
+            float err;
+            const float a = sphere_sdf_estimate(s, b, err);
+            cand = a - err <= ub;
+            if (cand) e = sphere_sdf_fast(s, S.radii[j], b);
+        }
+        best = masked_min_f64(e, __ballot(cand), best);
     }
-    return wave_min_f64(best);
+    return best;
 }
 
 // Scene.getDistance over all primitives (scene.ts:183-189 and the fallback scene.ts:173) for
@@ -153,10 +200,12 @@ __device__ double all_prims_wave(const SceneView &S, bool need, const Vec3f &q, 
 
 // BVH branch of Scene.getDistance (scene.ts:167-181); whole wave must call
 __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
-                                    uint32_t &count, int lane, bool coop, bool filter, bool use_grid) {
+                                    uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
+                                    unsigned long long *dbg_fallback_cycles) {
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     bool walk_tree = false;
+    int nn_cell = -1;  // grid cell of q when q lies inside the root box
     if (need && use_grid) {
         // BVH.getPrimitivesAt through the leaf grid: the leaves listed for p's cell are a superset
         // of the leaves whose box contains p; each is re-tested with the reference's inclusive
@@ -166,7 +215,8 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             const int cx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
             const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
             const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
-            const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
+            nn_cell = (cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx;
+            const uint32_t cell = S.pq_cells[nn_cell];
             const int ccnt = static_cast<int>(cell & 0xFFu);
             if (ccnt == 255) walk_tree = true;  // crowded cell: fall back to the tree walk below
             else {
@@ -202,10 +252,28 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             i = node.skip;
         }
     }
-    const bool fallback = need && found == 0;
-    const double all = all_prims_wave(S, fallback, q, lane, coop, filter);
+    bool fallback = need && found == 0;
+    bool served = false;
+    if (fallback && P.use_nn && nn_cell >= 0) {
+        // scene.ts:173 fallback through the cell's nearest-candidate list: every sphere that can
+        // attain the minimum for a point of this cell is in the list (rm_scene_host.cpp), so the
+        // minimum over the list equals the minimum over all N primitives; N are still counted.
+        const uint32_t cell = S.nn_cells[nn_cell];
+        const int ccnt = static_cast<int>(cell & 0xFFu);
+        if (ccnt != 255) {
+            closest = prims_min<true, uint16_t>(S.spheres, S.radii, S.nn_list + (cell >> 8), ccnt, q, RM_MAX_DIST, true);
+            served = true;
+        }
+    }
+#ifdef RM_STAMPS
+    const unsigned long long t_fb0 = __builtin_amdgcn_s_memtime();
+#endif
+    const double all = all_prims_wave(S, fallback && !served, q, lane, coop, filter);
+#ifdef RM_STAMPS
+    if (dbg_fallback_cycles) *dbg_fallback_cycles += __builtin_amdgcn_s_memtime() - t_fb0;
+#endif
     if (fallback) {
-        closest = all;
+        if (!served) closest = all;
         count += static_cast<uint32_t>(S.n_prims);
     } else if (need) {
         count += found;
@@ -382,7 +450,7 @@ __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &ti
 }
 
 template <int ACCEL, bool LDS>
-__global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) {
+__global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -395,6 +463,8 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     S.radii = P.radii;
     S.pq_cells = P.pq_cells;
     S.pq_list = P.pq_list;
+    S.nn_cells = P.nn_cells;
+    S.nn_list = P.nn_list;
     S.n_prims = P.n_prims;
     S.bvh_nodes = P.bvh_nodes;
     const bool use_grid = ACCEL == 2 && P.use_grid != 0;
@@ -406,6 +476,10 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
             if (use_grid) {
                 S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
                 S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
+                if (P.use_nn) {
+                    S.nn_cells = stage(smem, off, P.nn_cells, P.nn_cell_count);
+                    S.nn_list = stage(smem, off, P.nn_list, P.nn_list_count);
+                }
             }
         } else if (ACCEL == 1) {
             S.oct = stage(smem, off, P.oct, P.oct_nodes);
@@ -447,9 +521,8 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
     bool have_pixel = false;
     int px = 0, prow = 0;  // pixel column, tile-local row of the lane's pixel
     int loopi = 0;
-    double t = 0.0, depth = RM_MAX_DIST, d0 = 0.0;
+    double t = RM_MAX_DIST, d0 = 0.0;  // t: distance marched; after the march it is the returned depth
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    Vec3f hit = {0.f, 0.f, 0.f};
     Interval cur;
     cur.tEnter = 0.0;
     cur.tExit = 0.0;
@@ -458,19 +531,20 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
 
     // march finished with distance `dist_total` (raymarcher.ts:91-102)
     auto finish_march = [&](double dist_total) {
-        depth = dist_total;
-        hit = point_at(ray, depth);
-        phase = (depth >= RM_MAX_DIST) ? PH_DONE : PH_N0;
+        t = dist_total;
+        phase = (t >= RM_MAX_DIST) ? PH_DONE : PH_N0;
     };
 
+    RM_T0()
     for (;;) {
+        RM_T(7)
         // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
         // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
         const unsigned long long idle = __ballot(phase == PH_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle >= refill_at || n_idle == 64) {
             if (phase == PH_DONE && have_pixel) {
-                store_pixel(P, static_cast<size_t>(prow) * P.width + px, depth, nx, ny, nz, count, iters);
+                store_pixel(P, static_cast<size_t>(prow) * P.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;
             }
             if (!no_more && qpos >= Q.item_px) {
@@ -494,13 +568,22 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
                         iters = 0;
                         loopi = 0;
                         t = 0.0;
-                        depth = RM_MAX_DIST;
                         nx = ny = nz = 0.f;
                         phase = PH_MARCH;
                         if (ACCEL == 2) {
                             ri = make_ray_inv(ray);
+#ifdef RM_STAMPS
+                            const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
+#endif
                             haveCur = bvh_prologue(S, ray, ri, L, cur);
-                            if (!haveCur) phase = PH_DONE;  // bvh.ts:190-192: exactly MAX_DIST, zero normal
+#ifdef RM_STAMPS
+                            t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
+                            t_prev_ += __builtin_amdgcn_s_memtime() - t_pr0;
+#endif
+                            if (!haveCur) {  // bvh.ts:190-192: exactly MAX_DIST, zero normal
+                                t = RM_MAX_DIST;
+                                phase = PH_DONE;
+                            }
                         }
                     }
                 }
@@ -508,9 +591,10 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
             }
         }
         if (no_more && !__any(phase != PH_DONE)) {
-            if (have_pixel) store_pixel(P, static_cast<size_t>(prow) * P.width + px, depth, nx, ny, nz, count, iters);
+            if (have_pixel) store_pixel(P, static_cast<size_t>(prow) * P.width + px, t, nx, ny, nz, count, iters);
             break;
         }
+        RM_T(0)
 
         // ---- A: bookkeeping until this lane needs a distance (sphereTracer.ts:43-64) ------
         bool need = false;
@@ -569,24 +653,35 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
             }
         }
         if (phase >= PH_N0 && phase <= PH_N3) {  // raymarcher.ts:123-132 sample points
-            q = hit;
-            if (phase == PH_N1) q.x = to_f32(static_cast<double>(hit.x) - 0.01);
-            if (phase == PH_N2) q.y = to_f32(static_cast<double>(hit.y) - 0.01);
-            if (phase == PH_N3) q.z = to_f32(static_cast<double>(hit.z) - 0.01);
+            q = point_at(ray, t);  // hitPosition (raymarcher.ts:94-95), recomputed: 3 VGPRs fewer
+            if (phase == PH_N1) q.x = to_f32(static_cast<double>(q.x) - 0.01);
+            if (phase == PH_N2) q.y = to_f32(static_cast<double>(q.y) - 0.01);
+            if (phase == PH_N3) q.z = to_f32(static_cast<double>(q.z) - 0.01);
             if (ACCEL == 1) onode = oct_find(S, q);
             need = true;
         }
+        RM_T(1)
         if (!__any(need)) continue;  // every live ray just finished: go and refill
 
         // ---- B: one Scene.getDistance per needing lane --------------------------------------
         double dist;
-        if (ACCEL == 2) dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid);
+        if (ACCEL == 2) {
+#ifdef RM_STAMPS
+            unsigned long long fbc = 0;
+            dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid, &fbc);
+            t_acc_[4] += fbc;
+            t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
+#else
+            dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid, nullptr);
+#endif
+        }
         else if (ACCEL == 1) dist = need ? oct_distance_lane(S, onode, q, count, filter) : RM_MAX_DIST;
         else {
             dist = all_prims_wave(S, need, q, lane, coop, filter);
             if (need) count += static_cast<uint32_t>(S.n_prims);
         }
 
+        RM_T(2)
         // ---- C: consume -------------------------------------------------------------------------
         if (need) {
             if (phase == PH_MARCH) {
@@ -608,7 +703,9 @@ __global__ __launch_bounds__(256) void render_kernel_v2(const RmRenderParams P) 
                 phase = PH_DONE;
             }
         }
+        RM_T(3)
     }
+    RM_TEND()
 }
 
 size_t scene_lds_bytes(const RmRenderParams &p) {
@@ -617,6 +714,7 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
     if (p.accel == 2) {
         b += up(static_cast<size_t>(p.bvh_nodes) * sizeof(RmBvhNode)) + up(static_cast<size_t>(p.bvh_prim_count) * 4);
         if (p.use_grid) b += up(static_cast<size_t>(p.pq_cell_count) * 4) + up(static_cast<size_t>(p.pq_list_count) * 2 + 4);
+        if (p.use_grid && p.use_nn) b += up(static_cast<size_t>(p.nn_cell_count) * 4) + up(static_cast<size_t>(p.nn_list_count) * 2 + 4);
     } else if (p.accel == 1) {
         b += up(static_cast<size_t>(p.oct_nodes) * sizeof(RmOctNode)) + up(static_cast<size_t>(p.oct_prim_count) * 4);
     }

@@ -228,6 +228,53 @@ void build_point_query_grid(HostScene &s) {
         s.pq_cells[c] = static_cast<uint32_t>(s.pq_list.size() << 8) | static_cast<uint32_t>(n);
         s.pq_list.insert(s.pq_list.end(), per_cell[c].begin(), per_cell[c].end());
     }
+
+    // Nearest-candidate lists.  For a cell C (grown by 1 % like above) and sphere j with centre
+    // c_j, radius r_j:  lb_j = max(0, dist(C, c_j)) - r_j  <=  Sphere.sdf_j(p)  <=  maxdist(C, c_j) - r_j = ub_j
+    // for every p in C.  With U = min(10, min_j ub_j), a sphere with lb_j > U can never attain
+    // min(10, min_j sdf_j(p)) for p in C, so evaluating only {j : lb_j <= U + margin} gives the
+    // same minimum (min is order independent).  margin absorbs the difference between these
+    // real-number bounds and the reference's rounded arithmetic (~1e-15) by many orders.
+    const size_t n = s.spheres.size();
+    if (n == 0 || n >= 65536 || cells * n > 60000000ull) return;
+    s.nn_cells.assign(cells, 255);
+    const double margin = 1e-6;
+    std::vector<double> lb(n);
+    for (int z = 0; z < s.pq_dim[2]; ++z)
+        for (int y = 0; y < s.pq_dim[1]; ++y)
+            for (int x = 0; x < s.pq_dim[0]; ++x) {
+                const int ci[3] = {x, y, z};
+                double lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    const double w = s.pq_inv[k] > 0 ? 1.0 / double(s.pq_inv[k]) : 0.0;
+                    lo[k] = double(s.pq_origin[k]) + (ci[k] - 0.01) * w;
+                    hi[k] = double(s.pq_origin[k]) + (ci[k] + 1.01) * w;
+                    // border cells also receive the clamped indices of points outside the grid
+                    // range (only by rounding: the device tests the root box first), keep 1 % slack
+                }
+                double U = 10.0;
+                for (size_t j = 0; j < n; ++j) {
+                    const double c[3] = {s.spheres[j].cx, s.spheres[j].cy, s.spheres[j].cz};
+                    double dmin2 = 0, dmax2 = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double below = lo[k] - c[k], above = c[k] - hi[k];
+                        const double dmin = below > 0 ? below : (above > 0 ? above : 0.0);
+                        const double dmax = std::max(std::fabs(c[k] - lo[k]), std::fabs(c[k] - hi[k]));
+                        dmin2 += dmin * dmin;
+                        dmax2 += dmax * dmax;
+                    }
+                    lb[j] = std::sqrt(dmin2) - s.radii[j];
+                    const double ub = std::sqrt(dmax2) - s.radii[j];
+                    if (ub < U) U = ub;
+                }
+                std::vector<uint16_t> cand;
+                for (size_t j = 0; j < n; ++j)
+                    if (lb[j] <= U + margin) cand.push_back(static_cast<uint16_t>(j));
+                const size_t c_idx = (static_cast<size_t>(z) * s.pq_dim[1] + y) * s.pq_dim[0] + x;
+                if (cand.size() >= 255 || s.nn_list.size() + cand.size() >= (1u << 24)) continue;  // stays 255
+                s.nn_cells[c_idx] = static_cast<uint32_t>(s.nn_list.size() << 8) | static_cast<uint32_t>(cand.size());
+                s.nn_list.insert(s.nn_list.end(), cand.begin(), cand.end());
+            }
 }
 
 // ---- Octree (octree.ts:36-191) ----------------------------------------------------------

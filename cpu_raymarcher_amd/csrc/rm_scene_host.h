@@ -28,6 +28,10 @@ struct HostScene {
     float pq_origin[3] = {0, 0, 0}, pq_inv[3] = {0, 0, 0};
     std::vector<uint32_t> pq_cells;
     std::vector<uint16_t> pq_list;
+    // Same cells: spheres that can attain min_j Sphere.sdf for SOME point of the cell (the
+    // all-primitive fallback of scene.ts:173 then only evaluates these).  count 255 = no list.
+    std::vector<uint32_t> nn_cells;
+    std::vector<uint16_t> nn_list;
     std::vector<RmOctNode> oct;
     std::vector<int32_t> oct_prims;
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;

@@ -86,8 +86,12 @@ struct RmRenderParams {
     int32_t n_parts, part;     //      this launch renders the stripes of `part`, packed in increasing y
     int32_t reserved1;
     unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch
+    unsigned long long *stamps;   // diagnostic build (-DRM_STAMPS) only: 8 cycle accumulators
     const uint32_t *pq_cells;
     const uint16_t *pq_list;
+    const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
+    const uint16_t *nn_list;
+    int32_t nn_cell_count, nn_list_count, use_nn, reserved2;
     const RmSphere *spheres;
     const double *radii;
     const RmBvhNode *bvh;

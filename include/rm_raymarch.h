@@ -218,6 +218,10 @@ RM_API int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *o
  * binary32 triples (zeros, denormals, equal magnitudes included) and counts bitwise mismatches. */
 RM_API int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *mismatches);
 
+/* Diagnostic builds only (make EXTRA=-DRM_STAMPS): reads and clears eight per-section cycle
+ * accumulators of the v2 wave loop (all zero in the product build). */
+RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
+
 /* kernel-variant knobs for measurement (tile shape, LDS staging ...); unknown keys are
  * RM_E_INVALID.  Never changes results. */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);

@@ -45,7 +45,7 @@ def main():
     tr = R.SphereTracer()
     ref = None
     defaults = {k: ctx.get_option(k) for k in ("kernel", "tile_w", "filter", "nodes_in_lds", "list_cap", "coop", "grid",
-                                               "blocks_per_cu", "refill", "hw_xcd", "item_px")}
+                                               "blocks_per_cu", "refill", "hw_xcd", "item_px", "nn")}
     for v in variants:
         for k, val in defaults.items():
             ctx.set_option(k, val)

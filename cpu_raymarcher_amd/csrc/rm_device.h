@@ -29,8 +29,7 @@ __device__ __forceinline__ double hypot3(float lx, float ly, float lz) {
     const double ax = __builtin_fabs(static_cast<double>(lx));
     const double ay = __builtin_fabs(static_cast<double>(ly));
     const double az = __builtin_fabs(static_cast<double>(lz));
-    double big = ax > ay ? ax : ay;
-    big = az > big ? az : big;
+    const double big = __builtin_fmax(__builtin_fmax(ax, ay), az);  // no NaN among the operands
     if (big == 0.0) return 0.0;
     const double nx = ax / big, ny = ay / big, nz = az / big;
     double sum = nx * nx;
@@ -57,8 +56,7 @@ __device__ __forceinline__ double hypot3_shared_rcp(float lx, float ly, float lz
     const double ax = __builtin_fabs(static_cast<double>(lx));
     const double ay = __builtin_fabs(static_cast<double>(ly));
     const double az = __builtin_fabs(static_cast<double>(lz));
-    double big = ax > ay ? ax : ay;
-    big = az > big ? az : big;
+    const double big = __builtin_fmax(__builtin_fmax(ax, ay), az);
     if (big == 0.0) return 0.0;
     const double r0 = __builtin_amdgcn_rcp(big);
     const double e0 = __builtin_fma(-big, r0, 1.0);
@@ -112,8 +110,10 @@ __device__ __forceinline__ float sphere_sdf_estimate(const RmSphere &s, const Ve
 }
 
 // Math.min(candidate, closest) -- operands are never NaN here (inputs validated finite)
+// (v_min_f64; it differs from the select only for NaN or for the sign of a zero, neither of
+// which can reach an output: DESIGN.md section 2)
 __device__ __forceinline__ double min_dist(double candidate, double closest) {
-    return candidate < closest ? candidate : closest;
+    return __builtin_fmin(candidate, closest);
 }
 
 // min(closest, min over ids[0..n) -- or 0..n-1 when ids is null -- of Sphere.sdf), the loop of
@@ -210,15 +210,11 @@ __device__ __forceinline__ bool slab_inv(const float lo[3], const float hi[3], c
         if (ri.par[a]) {
             if (o[a] < lo[a] || o[a] > hi[a]) return false;
         } else {
-            double t0 = (static_cast<double>(lo[a]) - r.od[a]) * ri.inv[a];
-            double t1 = (static_cast<double>(hi[a]) - r.od[a]) * ri.inv[a];
-            if (t0 > t1) {
-                const double t = t0;
-                t0 = t1;
-                t1 = t;
-            }
-            tMin = tMin > t0 ? tMin : t0;
-            tMax = tMax < t1 ? tMax : t1;
+            const double ta = (static_cast<double>(lo[a]) - r.od[a]) * ri.inv[a];
+            const double tb = (static_cast<double>(hi[a]) - r.od[a]) * ri.inv[a];
+            const double t0 = __builtin_fmin(ta, tb), t1 = __builtin_fmax(ta, tb);  // if (t0 > t1) swap
+            tMin = __builtin_fmax(tMin, t0);  // Math.max / Math.min: operands are never NaN here
+            tMax = __builtin_fmin(tMax, t1);
             if (tMin > tMax) return false;
         }
     }

@@ -341,8 +341,8 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
             continue;
         }
         if ((node.leaf & 0xFF) > 0) {  // bvh.ts:165
-            const double cE = tE > 0.0 ? tE : 0.0;
-            const double cX = tX < RM_MAX_DIST ? tX : RM_MAX_DIST;
+            const double cE = __builtin_fmax(tE, 0.0);
+            const double cX = __builtin_fmin(tX, RM_MAX_DIST);
             if (L.cnt < L.cap) L.col[L.cnt * 64] = static_cast<uint16_t>(i);
             L.cnt++;
             if (!have || cE < first.tEnter) {
@@ -367,8 +367,8 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, con
             const RmBvhNode node = S.nodes[id];
             double tE, tX;
             slab_inv(node.lo, node.hi, r, ri, tE, tX);  // hit by construction; same arithmetic, same values
-            const double cE = tE > 0.0 ? tE : 0.0;
-            const double cX = tX < RM_MAX_DIST ? tX : RM_MAX_DIST;
+            const double cE = __builtin_fmax(tE, 0.0);
+            const double cX = __builtin_fmin(tX, RM_MAX_DIST);
             const bool after = cE > keyT || (cE == keyT && id > keyOrd);
             if (after && (!have || cE < out.tEnter)) {  // list is in traversal order: first seen wins ties
                 out.tEnter = cE;
@@ -393,8 +393,8 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, con
             continue;
         }
         if ((node.leaf & 0xFF) > 0) {
-            const double cE = tE > 0.0 ? tE : 0.0;
-            const double cX = tX < RM_MAX_DIST ? tX : RM_MAX_DIST;
+            const double cE = __builtin_fmax(tE, 0.0);
+            const double cX = __builtin_fmin(tX, RM_MAX_DIST);
             const bool after = cE > keyT || (cE == keyT && i > keyOrd);
             if (after && (!have || cE < out.tEnter)) {
                 out.tEnter = cE;

@@ -193,8 +193,8 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     if (job->height <= 0 || job->width < 0) return fail(ctx, RM_E_INVALID, "width must be >= 0 and height > 0");
     if (!std::isfinite(job->camera_pitch) || !std::isfinite(job->camera_yaw))
         return fail(ctx, RM_E_INVALID, "non-finite camera angle");
-    if (job->algorithm != RM_ALG_SPHERE_TRACER)
-        return fail(ctx, RM_E_UNSUPPORTED, "only the sphere tracer is implemented natively");
+    if (job->algorithm < RM_ALG_SPHERE_TRACER || job->algorithm > RM_ALG_ADAPTIVE_STEP_V3)
+        return fail(ctx, RM_E_INVALID, "unknown algorithm enum (use rm_algorithm_from_string)");
     int rc = ensure_scene(ctx, job->scene_preset_index, job->acceleration_structure);
     if (rc) return rc;
     std::memset(&p, 0, sizeof p);
@@ -202,6 +202,10 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.height = job->height;
     p.y_start = job->y_start;
     p.y_end = job->y_end;
+    p.algorithm = job->algorithm;
+    // NaN stands for JS `undefined`: the constructors' defaults (adaptiveStepV2.ts:13, fixedStep.ts:13)
+    p.overshoot = std::isnan(job->overshoot_factor) ? 1.2 : job->overshoot_factor;
+    p.step_size = std::isnan(job->step_size) ? 0.1 : job->step_size;
     p.local_rows = job->y_end > job->y_start ? job->y_end - job->y_start : 0;
     p.stripe_rows = 0;
     p.n_parts = 1;
@@ -222,6 +226,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.filter = static_cast<int32_t>(ctx->opt_filter);
     p.variant = static_cast<int32_t>(ctx->opt_kernel);
     if (p.variant == 0) p.variant = ctx->host.accel == RM_ACCEL_OCTREE ? 1 : 2;
+    if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
     p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
     p.coop = static_cast<int32_t>(ctx->opt_coop);
     p.bvh_prim_count = static_cast<int32_t>(ctx->host.bvh_prims.size());

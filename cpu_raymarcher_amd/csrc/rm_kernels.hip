@@ -226,7 +226,113 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
     return t;
 }
 
+// The four other marchers of the Algorithm plugin (raymarchWorker.ts:49-68) share the accel
+// prologue and skip protocol of the sphere tracer and differ in the step rule:
+//   1 FixedStep       fixedStep.ts:21-94        MAX_STEPS 200, returns MAX_DIST unless it hit
+//   2 AdaptiveStep    adaptiveStep.ts:22-105    MAX_STEPS 200, step = clamp(0.8 d, 0.025, 0.5) or 0.01 near
+//   3 AdaptiveStepV2  adaptiveStepV2.ts:22-124  overshoot by overshootFactor, step back when spheres do not overlap
+//   4 AdaptiveStepV3  adaptiveStepV3.ts:22-137  as V2 plus the "bridging" third evaluation
 template <int ACCEL>
+__device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
+    const int alg = P.algorithm;
+    const int max_steps = (alg == 1 || alg == 2) ? 200 : 100;
+    const double FIXED_STEP_SIZE = 0.1, STEP_SCALE = 0.8;
+    const double MIN_STEP = FIXED_STEP_SIZE * 0.25, MAX_STEP = FIXED_STEP_SIZE * 5.0;
+    const double NEAR_DIST = 0.1, NEAR_STEP = 0.01;
+    double t = 0.0, prevSDF = 0.0, prevStep = 0.0;
+    bool hit = false;
+    Interval cur;
+    bool haveCur = false;
+    if (ACCEL == 2) {
+        haveCur = bvh_next_interval(P, ray, -__builtin_inf(), -1, cur);
+        if (!haveCur) return RM_MAX_DIST;
+    }
+    for (int i = 0; i < max_steps; ++i) {
+        Vec3f p = point_at(ray, t);
+        int onode = -1;
+        double skip = 0.0;
+        if (ACCEL == 2) {  // BVH.onRayMarchStep (bvh.ts:204-240)
+            if (!haveCur) return RM_MAX_DIST;
+            if (t < cur.tEnter) skip = cur.tEnter - t;
+            else if (t > cur.tExit) {
+                const Interval prev = cur;
+                haveCur = bvh_next_interval(P, ray, prev.tEnter, prev.ord, cur);
+                if (!haveCur) return RM_MAX_DIST;
+                if (cur.tEnter > t) skip = cur.tEnter - t;
+            }
+        } else if (ACCEL == 1) {
+            onode = oct_find(P, p);
+            if (onode >= 0) skip = oct_skip(P.oct[onode], ray, t);
+        }
+        if (skip > 0.0) {
+            t += skip;
+            if (t > RM_MAX_DIST) break;
+            prevSDF = 0.0;  // adaptiveStepV2.ts:73-74 (harmless for the marchers without this state)
+            prevStep = 0.0;
+            continue;
+        }
+        const double dist = ACCEL == 1 ? oct_node_distance(P, onode, p, count) : scene_distance<ACCEL>(P, p, count);
+        iters += 1;
+        if (alg == 1 || alg == 2) {
+            if (dist < RM_EPSILON) {
+                hit = true;
+                break;
+            }
+            double step;
+            if (alg == 1) step = P.step_size;
+            else if (dist < NEAR_DIST) step = NEAR_STEP;
+            else {
+                step = STEP_SCALE * dist;
+                if (step < MIN_STEP) step = MIN_STEP;
+                if (step > MAX_STEP) step = MAX_STEP;
+            }
+            t += step;
+            if (t > RM_MAX_DIST) break;
+            continue;
+        }
+        // AdaptiveStepV2 / V3
+        if (dist < RM_EPSILON) break;
+        if (t > RM_MAX_DIST) break;
+        if (i == 0 || prevSDF == 0.0) {
+            t += dist;
+            prevSDF = dist;
+            prevStep = dist;
+            continue;
+        }
+        if (prevStep <= (prevSDF + dist)) {  // spheresOverlapped
+            const double step = dist * P.overshoot;
+            t += step;
+            prevSDF = dist;
+            prevStep = step;
+            continue;
+        }
+        if (alg == 3) {  // adaptiveStepV2.ts:108-114
+            t -= prevStep;
+            t += prevSDF;
+            prevStep = prevSDF;
+            continue;
+        }
+        // adaptiveStepV3.ts:103-130
+        const double originalPos = t - prevStep;
+        t = originalPos + prevSDF;
+        p = point_at(ray, t);
+        const double d3 = scene_distance<ACCEL>(P, p, count);
+        iters += 1;
+        if (prevSDF + dist + d3 >= prevStep) {
+            t = originalPos + prevStep + dist;
+            prevSDF = dist;
+            prevStep = dist;
+            continue;
+        }
+        prevSDF = d3;
+        prevStep = d3;
+        t += d3;
+    }
+    if (alg == 1 || alg == 2) return hit ? t : RM_MAX_DIST;
+    return t;
+}
+
+template <int ACCEL, bool OTHER>
 __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     // wave tile: tile_w x (64 / tile_w); four waves stacked vertically per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,7 +367,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     ray.od[2] = P.origin_d[2];
 
     uint32_t count = 0, iters = 0;
-    const double depth = ray_march<ACCEL>(P, ray, count, iters);
+    const double depth = OTHER ? ray_march_other<ACCEL>(P, ray, count, iters) : ray_march<ACCEL>(P, ray, count, iters);
     uint8_t nb[3];
     normal_and_store<ACCEL>(P, ray, depth, count, nb);
     const uint8_t db = u8clamp(depth);
@@ -436,14 +542,18 @@ hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long lo
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const int rows = p.local_rows;
     if (rows <= 0 || p.width <= 0) return hipSuccess;
-    if (p.variant == 2) return rm_launch_render_v2(p, stream);
+    if (p.variant == 2 && p.algorithm == 0) return rm_launch_render_v2(p, stream);
     const int tw = p.tile_w, th = 64 / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
-    if (p.accel == 2) hipLaunchKernelGGL(render_kernel<2>, grid, block, 0, stream, p);
-    else if (p.accel == 1) hipLaunchKernelGGL(render_kernel<1>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(render_kernel<0>, grid, block, 0, stream, p);
+#define RM_V1(A, O) hipLaunchKernelGGL((render_kernel<A, O>), grid, block, 0, stream, p)
+    if (p.algorithm == 0) {
+        if (p.accel == 2) RM_V1(2, false); else if (p.accel == 1) RM_V1(1, false); else RM_V1(0, false);
+    } else {
+        if (p.accel == 2) RM_V1(2, true); else if (p.accel == 1) RM_V1(1, true); else RM_V1(0, true);
+    }
+#undef RM_V1
     return hipGetLastError();
 }
 

@@ -91,7 +91,10 @@ struct RmRenderParams {
     const uint16_t *pq_list;
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
-    int32_t nn_cell_count, nn_list_count, use_nn, reserved2;
+    int32_t nn_cell_count, nn_list_count, use_nn;
+    int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)
+    double overshoot;    // AdaptiveStepV2/V3 overshootFactor (default 1.2)
+    double step_size;    // FixedStep stepSize (default 0.1)
     const RmSphere *spheres;
     const double *radii;
     const RmBvhNode *bvh;

@@ -107,8 +107,9 @@ def _job(scene, width, height, time, yStart, yEnd, algorithm, overshootFactor=No
     j.algorithm = N.lib().rm_algorithm_from_string(str(algorithm).encode())
     j.scene_preset_index = scene.preset_for_job
     j.acceleration_structure = scene.accel_enum
-    j.overshoot_factor = float(overshootFactor) if overshootFactor is not None else 0.0
-    j.step_size = float(stepSize) if stepSize is not None else 0.0
+    # None mirrors JS `undefined` (constructor defaults 1.2 / 0.1); the ABI encodes it as NaN
+    j.overshoot_factor = float(overshootFactor) if overshootFactor is not None else float("nan")
+    j.step_size = float(stepSize) if stepSize is not None else float("nan")
     return j
 
 
@@ -135,14 +136,14 @@ class SphereTracer(Raymarcher):  # cpu_algorithms/sphereTracer.ts
     algorithm = "sphere-tracer"
 
 
-class FixedStep(Raymarcher):  # not native yet: RM_E_UNSUPPORTED -> RmUnsupported
+class FixedStep(Raymarcher):  # cpu_algorithms/fixedStep.ts
     algorithm = "fixed-step"
 
     def __init__(self, stepSize=None):
         self.stepSize = stepSize
 
 
-class AdaptiveStep(Raymarcher):
+class AdaptiveStep(Raymarcher):  # cpu_algorithms/adaptiveStep.ts
     algorithm = "adaptive-step"
 
 

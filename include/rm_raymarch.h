@@ -41,8 +41,8 @@ typedef struct rm_ctx rm_ctx;
 typedef enum rm_status {
     RM_OK = 0,
     RM_E_INVALID = -1,     /* null pointer, negative size, non-finite camera ...            */
-    RM_E_UNSUPPORTED = -2, /* preset with non-sphere primitives; marcher other than sphere  */
-                           /* tracer (host may fall back to its own CPU path)               */
+    RM_E_UNSUPPORTED = -2, /* preset with non-sphere primitives or SDF operators (the host  */
+                           /* keeps its own CPU path for those jobs)                        */
     RM_E_NO_DEVICE = -3,   /* ctx was created host-only, or no HIP device                   */
     RM_E_HIP = -4,         /* a HIP runtime call failed; rm_last_error has the text         */
     RM_E_NO_SCENE = -5,    /* render requested before any scene was set                     */
@@ -88,8 +88,8 @@ typedef struct rm_job {
     int32_t scene_preset_index;     /* clamped to [0, 18] (scene.ts:39) or RM_SCENE_UPLOADED */
     int32_t acceleration_structure; /* rm_accel                                          */
     int32_t reserved;
-    double  overshoot_factor;       /* Job.overshootFactor (unused by sphere tracer)     */
-    double  step_size;              /* Job.stepSize        (unused by sphere tracer)     */
+    double  overshoot_factor;       /* Job.overshootFactor, AdaptiveStepV2/V3; NaN = JS undefined -> 1.2 */
+    double  step_size;              /* Job.stepSize, FixedStep;               NaN = JS undefined -> 0.1 */
 } rm_job;
 
 /* what rm_scene_get_info reports about the built acceleration structure */

@@ -10,7 +10,8 @@ const out = process.argv[3];
 const H = cfg.height, W = cfg.width;
 const job = { width: W, height: H, time: 0, yStart: cfg.yStart === undefined ? 0 : cfg.yStart,
   yEnd: cfg.yEnd === undefined ? H : cfg.yEnd, camera: { pitch: cfg.pitch || 0, yaw: cfg.yaw || 0 },
-  algorithm: cfg.algorithm || 'sphere-tracer', scenePresetIndex: cfg.preset, accelerationStructure: cfg.accel };
+  algorithm: cfg.algorithm || 'sphere-tracer', scenePresetIndex: cfg.preset, accelerationStructure: cfg.accel,
+  overshootFactor: cfg.overshootFactor, stepSize: cfg.stepSize };
 let res;
 try { res = R.onmessage(job); } catch (e) { process.stdout.write(JSON.stringify({ error: e.message, code: e.code }) + '\n'); process.exit(e.code === -2 ? 3 : 1); }
 const rows = job.yEnd - job.yStart;

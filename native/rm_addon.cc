@@ -8,6 +8,7 @@
 // the caller keeps its CPU path for that job), lastError() has the text.
 #include <node_api.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -67,8 +68,8 @@ rm_job job_from_js(napi_env env, napi_value j) {
     job.algorithm = rm_algorithm_from_string(str_prop(env, j, "algorithm").c_str());
     job.scene_preset_index = static_cast<int32_t>(num_prop(env, j, "scenePresetIndex", 0));
     job.acceleration_structure = rm_accel_from_string(str_prop(env, j, "accelerationStructure").c_str());
-    job.overshoot_factor = num_prop(env, j, "overshootFactor", 0);
-    job.step_size = num_prop(env, j, "stepSize", 0);
+    job.overshoot_factor = num_prop(env, j, "overshootFactor", NAN);  // undefined -> constructor default
+    job.step_size = num_prop(env, j, "stepSize", NAN);
     return job;
 }
 

@@ -45,6 +45,9 @@ def lib():
         L.ro_run_raymarcher.restype = C.c_int
         L.ro_run_raymarcher.argtypes = [C.c_void_p, C.c_char_p] + [C.c_void_p] * 4 + \
             [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.ro_run_raymarcher_ex.restype = C.c_int
+        L.ro_run_raymarcher_ex.argtypes = [C.c_void_p, C.c_char_p] + [C.c_void_p] * 4 + \
+            [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double]
         L.ro_shade.argtypes = [C.c_char_p] + [C.c_void_p] * 5 + [C.c_int, C.c_int]
         L.ro_diagnostics.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ro_scene_stats.argtypes = [C.c_void_p, C.c_void_p]
@@ -122,7 +125,8 @@ class OracleScene:
         d = lib().ro_scene_distance(self._h, _p(pos), C.byref(cnt))
         return d, cnt.value
 
-    def render(self, width, height, y_start=0, y_end=None, algorithm="sphere-tracer", time=0.0):
+    def render(self, width, height, y_start=0, y_end=None, algorithm="sphere-tracer", time=0.0,
+               overshoot_factor=None, step_size=None):
         """runRaymarcher (reference src/cpu_algorithms/raymarcher.ts:46-109): tile-local buffers."""
         if y_end is None:
             y_end = height
@@ -131,10 +135,13 @@ class OracleScene:
         normal = np.zeros(width * rows * 3, np.uint8)
         sdf = np.zeros(width * rows, np.uint16)
         iters = np.zeros(width * rows, np.uint16)
-        rc = lib().ro_run_raymarcher(self._h, algorithm.encode(), _p(depth), _p(normal), _p(sdf),
-                                     _p(iters), width, height, float(time), y_start, y_end)
+        nan = float("nan")
+        rc = lib().ro_run_raymarcher_ex(self._h, algorithm.encode(), _p(depth), _p(normal), _p(sdf),
+                                        _p(iters), width, height, float(time), y_start, y_end,
+                                        nan if overshoot_factor is None else float(overshoot_factor),
+                                        nan if step_size is None else float(step_size))
         if rc != 0:
-            raise NotImplementedError("oracle covers the sphere tracer only (algorithm=%r)" % algorithm)
+            raise RuntimeError("ro_run_raymarcher_ex failed (%d)" % rc)
         return depth, normal, sdf, iters
 
 

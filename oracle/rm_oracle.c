@@ -871,61 +871,194 @@ static inline double get_scene_distance(const ro_scene *s, const float *pos, uin
     return d;
 }
 
-#define MAX_STEPS 100
 #define MAX_DIST 10.0
 #define EPSILON 0.001
 
-/* sphereTracer.ts:15-83 rayMarch */
+/* The accel prologue and step callback every marcher shares (sphereTracer.ts:26-64,
+ * fixedStep.ts:33-72, adaptiveStep.ts:34-72, adaptiveStepV2.ts:37-76, adaptiveStepV3.ts:34-69). */
+typedef struct {
+    int haveState;  /* accelState truthy */
+    int nIntervals, curIdx;
+} AccelState;
+
+/* onRayMarchStart; returns 0 when the structure says "terminate" (bvh.ts:190-192) */
+static int accel_start(const ro_scene *s, const float *origin, const float *dir, Scratch *sc, AccelState *st) {
+    st->haveState = 0; st->nIntervals = 0; st->curIdx = 0;
+    if (s->accel == ACCEL_BVH && s->bvh) {
+        st->nIntervals = bvh_find_intervals(s, origin, dir, 0, MAX_DIST, sc->intervals, sc->stack);
+        if (st->nIntervals == 0) return 0;
+        st->haveState = 1;
+    } else if (s->accel == ACCEL_OCTREE && s->octree) {
+        st->haveState = 1; /* {data: null} is truthy, octree.ts:281-284 */
+    }
+    return 1;
+}
+
+/* onRayMarchStep: 0 = march normally, > 0 = skip, -1 = terminate */
+static double accel_step(const ro_scene *s, const float *origin, const float *dir, double totalDist,
+                         Scratch *sc, AccelState *st) {
+    if (!st->haveState) return 0;
+    if (s->accel == ACCEL_BVH) { /* bvh.ts:204-240 */
+        if (st->curIdx >= st->nIntervals) return -1;
+        const Interval *cur = &sc->intervals[st->curIdx];
+        if (totalDist < cur->tEnter) return cur->tEnter - totalDist;
+        if (totalDist > cur->tExit) {
+            st->curIdx++;
+            if (st->curIdx < st->nIntervals) {
+                const Interval *nx = &sc->intervals[st->curIdx];
+                if (nx->tEnter > totalDist) return nx->tEnter - totalDist;
+            } else return -1;
+        }
+        return 0;
+    }
+    return oct_marchRay(s, origin, dir, totalDist); /* octree.ts:286-294 */
+}
+
+/* sphereTracer.ts:15-83 rayMarch (MAX_STEPS = 100) */
 static double sphere_tracer_march(const ro_scene *s, const float *origin, const float *dir,
                                   uint16_t *sdfCell, uint16_t *iterCell, Scratch *sc) {
     double totalDist = 0;
-    int nIntervals = 0, curIdx = 0;
-    int haveState = 0; /* accelState truthy */
-    if (s->accel == ACCEL_BVH && s->bvh) {
-        /* bvh.ts:181-202 onRayMarchStart */
-        nIntervals = bvh_find_intervals(s, origin, dir, 0, MAX_DIST, sc->intervals, sc->stack);
-        if (nIntervals == 0) return MAX_DIST; /* terminate */
-        haveState = 1;
-    } else if (s->accel == ACCEL_OCTREE && s->octree) {
-        haveState = 1; /* {data: null} is truthy, octree.ts:281-284 */
-    }
-    for (int i = 0; i < MAX_STEPS; i++) {
+    AccelState st;
+    if (!accel_start(s, origin, dir, sc, &st)) return MAX_DIST;
+    for (int i = 0; i < 100; i++) {
         float p[3];
         vec3_scaleAndAdd(p, origin, dir, totalDist);
-        if (haveState) {
-            double skip = 0;
-            if (s->accel == ACCEL_BVH) {
-                /* bvh.ts:204-240 onRayMarchStep */
-                if (curIdx >= nIntervals) skip = -1;
-                else {
-                    const Interval *cur = &sc->intervals[curIdx];
-                    if (totalDist < cur->tEnter) skip = cur->tEnter - totalDist;
-                    else {
-                        skip = 0;
-                        if (totalDist > cur->tExit) {
-                            curIdx++;
-                            if (curIdx < nIntervals) {
-                                const Interval *nx = &sc->intervals[curIdx];
-                                if (nx->tEnter > totalDist) skip = nx->tEnter - totalDist;
-                            } else skip = -1;
-                        }
-                    }
-                }
-            } else {
-                skip = oct_marchRay(s, origin, dir, totalDist); /* octree.ts:286-294 */
-            }
-            if (skip == -1) return MAX_DIST;
-            else if (skip > 0) {
-                totalDist += skip;
-                if (totalDist > MAX_DIST) break;
-                continue;
-            }
+        double skip = accel_step(s, origin, dir, totalDist, sc, &st);
+        if (skip == -1) return MAX_DIST;
+        else if (skip > 0) {
+            totalDist += skip;
+            if (totalDist > MAX_DIST) break;
+            continue;
         }
         double dist = get_scene_distance(s, p, sdfCell, sc);
         totalDist += dist;
         *iterCell = (uint16_t)(*iterCell + 1);
         if (dist < EPSILON) break;
         if (totalDist > MAX_DIST) break;
+    }
+    return totalDist;
+}
+
+/* fixedStep.ts:21-94 (MAX_STEPS = 200; returns MAX_DIST unless it hit) */
+static double fixed_step_march(const ro_scene *s, const float *origin, const float *dir, uint16_t *sdfCell,
+                               uint16_t *iterCell, Scratch *sc, double stepSize) {
+    double totalDist = 0;
+    int hit = 0;
+    AccelState st;
+    if (!accel_start(s, origin, dir, sc, &st)) return MAX_DIST;
+    for (int i = 0; i < 200; i++) {
+        float p[3];
+        vec3_scaleAndAdd(p, origin, dir, totalDist);
+        double skip = accel_step(s, origin, dir, totalDist, sc, &st);
+        if (skip == -1) return MAX_DIST;
+        else if (skip > 0) {
+            totalDist += skip;
+            if (totalDist > MAX_DIST) break;
+            continue;
+        }
+        double dist = get_scene_distance(s, p, sdfCell, sc);
+        *iterCell = (uint16_t)(*iterCell + 1);
+        if (dist < EPSILON) { hit = 1; break; }
+        totalDist += stepSize;
+        if (totalDist > MAX_DIST) break;
+    }
+    return hit ? totalDist : MAX_DIST;
+}
+
+/* adaptiveStep.ts:22-105 (MAX_STEPS = 200) */
+static double adaptive_step_march(const ro_scene *s, const float *origin, const float *dir, uint16_t *sdfCell,
+                                  uint16_t *iterCell, Scratch *sc) {
+    const double FIXED_STEP_SIZE = 0.1, STEP_SCALE = 0.8;
+    const double MIN_STEP = FIXED_STEP_SIZE * 0.25, MAX_STEP = FIXED_STEP_SIZE * 5.0;
+    const double NEAR_DIST = 0.1, NEAR_STEP = 0.01;
+    double totalDist = 0;
+    int hit = 0;
+    AccelState st;
+    if (!accel_start(s, origin, dir, sc, &st)) return MAX_DIST;
+    for (int i = 0; i < 200; i++) {
+        float p[3];
+        vec3_scaleAndAdd(p, origin, dir, totalDist);
+        double skip = accel_step(s, origin, dir, totalDist, sc, &st);
+        if (skip == -1) return MAX_DIST;
+        else if (skip > 0) {
+            totalDist += skip;
+            if (totalDist > MAX_DIST) break;
+            continue;
+        }
+        double dist = get_scene_distance(s, p, sdfCell, sc);
+        *iterCell = (uint16_t)(*iterCell + 1);
+        if (dist < EPSILON) { hit = 1; break; }
+        double step;
+        if (dist < NEAR_DIST) step = NEAR_STEP;
+        else {
+            step = STEP_SCALE * dist;
+            if (step < MIN_STEP) step = MIN_STEP;
+            if (step > MAX_STEP) step = MAX_STEP;
+        }
+        totalDist += step;
+        if (totalDist > MAX_DIST) break;
+    }
+    return hit ? totalDist : MAX_DIST;
+}
+
+/* adaptiveStepV2.ts:22-124 (v3 == 0) and adaptiveStepV3.ts:22-137 (v3 == 1); MAX_STEPS = 100 */
+static double adaptive_v23_march(const ro_scene *s, const float *origin, const float *dir, uint16_t *sdfCell,
+                                 uint16_t *iterCell, Scratch *sc, double overshootFactor, int v3) {
+    double totalDist = 0, prevSDF = 0, prevStep = 0;
+    AccelState st;
+    if (!accel_start(s, origin, dir, sc, &st)) return MAX_DIST;
+    for (int i = 0; i < 100; i++) {
+        float p[3];
+        vec3_scaleAndAdd(p, origin, dir, totalDist);
+        double skip = accel_step(s, origin, dir, totalDist, sc, &st);
+        if (skip == -1) return MAX_DIST;
+        else if (skip > 0) {
+            totalDist += skip;
+            if (totalDist > MAX_DIST) break;
+            prevSDF = 0;
+            prevStep = 0;
+            continue;
+        }
+        double newSDF = get_scene_distance(s, p, sdfCell, sc);
+        *iterCell = (uint16_t)(*iterCell + 1);
+        if (newSDF < EPSILON) break;
+        if (totalDist > MAX_DIST) break;
+        if (i == 0 || prevSDF == 0) {
+            double step = newSDF;
+            totalDist += step;
+            prevSDF = newSDF;
+            prevStep = step;
+            continue;
+        }
+        int spheresOverlapped = prevStep <= (prevSDF + newSDF);
+        if (spheresOverlapped) {
+            double step = newSDF * overshootFactor;
+            totalDist += step;
+            prevSDF = newSDF;
+            prevStep = step;
+            continue;
+        }
+        if (!v3) { /* adaptiveStepV2.ts:108-114 */
+            totalDist -= prevStep;
+            totalDist += prevSDF;
+            prevStep = prevSDF;
+            continue;
+        }
+        /* adaptiveStepV3.ts:103-130 */
+        double originalPos = totalDist - prevStep;
+        totalDist = originalPos + prevSDF;
+        vec3_scaleAndAdd(p, origin, dir, totalDist);
+        double d3 = get_scene_distance(s, p, sdfCell, sc);
+        *iterCell = (uint16_t)(*iterCell + 1);
+        if (prevSDF + newSDF + d3 >= prevStep) {
+            totalDist = originalPos + prevStep + newSDF;
+            prevSDF = newSDF;
+            prevStep = newSDF;
+            continue;
+        }
+        prevSDF = d3;
+        prevStep = d3;
+        totalDist += d3;
     }
     return totalDist;
 }
@@ -955,12 +1088,16 @@ static int parse_algorithm(const char *a) {
 }
 
 /* raymarcher.ts:46-109 runRaymarcher (+ raymarchWorker.ts:33-92 algorithm pick).
- * Returns 0, or -1 for the marchers this restatement does not cover. */
-int ro_run_raymarcher(const ro_scene *s, const char *algorithm, uint8_t *depthBuffer,
-                      uint8_t *normalBuffer, uint16_t *sdfBuffer, uint16_t *iterBuffer,
-                      int width, int height, double time, int yStart, int yEnd) {
+ * overshootFactor / stepSize: NaN stands for JS `undefined` (constructor defaults 1.2 / 0.1,
+ * adaptiveStepV2.ts:13, fixedStep.ts:13). */
+int ro_run_raymarcher_ex(const ro_scene *s, const char *algorithm, uint8_t *depthBuffer,
+                         uint8_t *normalBuffer, uint16_t *sdfBuffer, uint16_t *iterBuffer,
+                         int width, int height, double time, int yStart, int yEnd,
+                         double overshootFactor, double stepSize) {
     (void)time; /* scene.updateTime: no animated primitives among spheres */
-    if (parse_algorithm(algorithm) != 0) return -1;
+    const int alg = parse_algorithm(algorithm);
+    if (overshootFactor != overshootFactor) overshootFactor = 1.2;
+    if (stepSize != stepSize) stepSize = 0.1;
     /* raymarcher.ts:62-67 */
     float rotMat3[9];
     const float *ct = s->cameraTransform;
@@ -988,7 +1125,15 @@ int ro_run_raymarcher(const ro_scene *s, const char *algorithm, uint8_t *depthBu
             vec3_transformMat3(rayDir, rayDir, rotMat3);
             vec3_normalize(rayDir, rayDir);
 
-            double depth = sphere_tracer_march(s, rayOrigin, rayDir, &sdfBuffer[idx], &iterBuffer[idx], &sc);
+            double depth;
+            uint16_t *sc_ = &sdfBuffer[idx], *ic_ = &iterBuffer[idx];
+            switch (alg) {
+            case 1: depth = fixed_step_march(s, rayOrigin, rayDir, sc_, ic_, &sc, stepSize); break;
+            case 2: depth = adaptive_step_march(s, rayOrigin, rayDir, sc_, ic_, &sc); break;
+            case 3: depth = adaptive_v23_march(s, rayOrigin, rayDir, sc_, ic_, &sc, overshootFactor, 0); break;
+            case 4: depth = adaptive_v23_march(s, rayOrigin, rayDir, sc_, ic_, &sc, overshootFactor, 1); break;
+            default: depth = sphere_tracer_march(s, rayOrigin, rayDir, sc_, ic_, &sc);
+            }
 
             float hit[3];
             vec3_scaleAndAdd(hit, rayOrigin, rayDir, depth);
@@ -1002,6 +1147,13 @@ int ro_run_raymarcher(const ro_scene *s, const char *algorithm, uint8_t *depthBu
     }
     free(sc.cand); free(sc.intervals); free((void *)sc.stack);
     return 0;
+}
+
+int ro_run_raymarcher(const ro_scene *s, const char *algorithm, uint8_t *depthBuffer,
+                      uint8_t *normalBuffer, uint16_t *sdfBuffer, uint16_t *iterBuffer,
+                      int width, int height, double time, int yStart, int yEnd) {
+    return ro_run_raymarcher_ex(s, algorithm, depthBuffer, normalBuffer, sdfBuffer, iterBuffer, width, height, time,
+                                yStart, yEnd, NAN, NAN);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -324,7 +324,7 @@ function sceneDistance(S, p, tally) { // scene.ts:144-190; tally[0] += evaluatio
 }
 
 // ---------------------------------------------------------------- tile render
-function renderTile(S, cam, W, H, y0, y1) {
+function renderTile(S, cam, W, H, y0, y1, algorithm, overshootFactor, stepSize) {
   const rows = Math.max(0, y1 - y0);
   const depth = new Uint8ClampedArray(W * rows), normal = new Uint8ClampedArray(W * rows * 3);
   const sdf = new Uint16Array(W * rows), iters = new Uint16Array(W * rows);
@@ -334,25 +334,37 @@ function renderTile(S, cam, W, H, y0, y1) {
   const tally = [0];
   function dist(at, px) { tally[0] = 0; const v = sceneDistance(S, at, tally); sdf[px] += tally[0]; return v; }
 
-  function march(px) { // sphereTracer.ts:15-83
-    let t = 0, list = null, cur = 0;
-    if (S.accel === 'BVH') { list = bvhIntervals(S.bvh, o, d, 0, 10); if (list.length === 0) return 10; }
-    for (let i = 0; i < 100; i++) {
-      p[0] = o[0] + d[0] * t; p[1] = o[1] + d[1] * t; p[2] = o[2] + d[2] * t;
-      if (S.accel !== 'None') {
-        let skip = 0;
-        if (S.accel === 'BVH') {
-          if (cur >= list.length) skip = -1;
-          else if (t < list[cur].a) skip = list[cur].a - t;
-          else if (t > list[cur].b) {
-            cur++;
-            if (cur < list.length) { if (list[cur].a > t) skip = list[cur].a - t; }
-            else skip = -1;
-          }
-        } else skip = octSkip(S.oct, o, d, t);
-        if (skip === -1) return 10;
-        if (skip > 0) { t += skip; if (t > 10) break; continue; }
+  // accel prologue / step callback shared by the five marchers
+  let list = null, cur = 0;
+  function accelStart() {
+    list = null; cur = 0;
+    if (S.accel === 'BVH') { list = bvhIntervals(S.bvh, o, d, 0, 10); if (list.length === 0) return false; }
+    return true;
+  }
+  function accelStep(t) { // 0: march, > 0: skip, -1: terminate
+    if (S.accel === 'None') return 0;
+    if (S.accel === 'BVH') {
+      if (cur >= list.length) return -1;
+      if (t < list[cur].a) return list[cur].a - t;
+      if (t > list[cur].b) {
+        cur++;
+        if (cur < list.length) { if (list[cur].a > t) return list[cur].a - t; }
+        else return -1;
       }
+      return 0;
+    }
+    return octSkip(S.oct, o, d, t);
+  }
+  function at(t) { p[0] = o[0] + d[0] * t; p[1] = o[1] + d[1] * t; p[2] = o[2] + d[2] * t; return p; }
+
+  function marchSphere(px) { // sphereTracer.ts:15-83
+    let t = 0;
+    if (!accelStart()) return 10;
+    for (let i = 0; i < 100; i++) {
+      at(t);
+      const skip = accelStep(t);
+      if (skip === -1) return 10;
+      if (skip > 0) { t += skip; if (t > 10) break; continue; }
       const dd = dist(p, px);
       t += dd;
       iters[px] += 1;
@@ -360,6 +372,76 @@ function renderTile(S, cam, W, H, y0, y1) {
       if (t > 10) break;
     }
     return t;
+  }
+  function marchFixed(px, stepSize) { // fixedStep.ts:21-94
+    let t = 0, hit = false;
+    if (!accelStart()) return 10;
+    for (let i = 0; i < 200; i++) {
+      at(t);
+      const skip = accelStep(t);
+      if (skip === -1) return 10;
+      if (skip > 0) { t += skip; if (t > 10) break; continue; }
+      const dd = dist(p, px);
+      iters[px] += 1;
+      if (dd < 0.001) { hit = true; break; }
+      t += stepSize;
+      if (t > 10) break;
+    }
+    return hit ? t : 10;
+  }
+  function marchAdaptive(px) { // adaptiveStep.ts:22-105
+    const FIXED = 0.1, MINS = FIXED * 0.25, MAXS = FIXED * 5.0;
+    let t = 0, hit = false;
+    if (!accelStart()) return 10;
+    for (let i = 0; i < 200; i++) {
+      at(t);
+      const skip = accelStep(t);
+      if (skip === -1) return 10;
+      if (skip > 0) { t += skip; if (t > 10) break; continue; }
+      const dd = dist(p, px);
+      iters[px] += 1;
+      if (dd < 0.001) { hit = true; break; }
+      let step;
+      if (dd < 0.1) step = 0.01;
+      else { step = 0.8 * dd; if (step < MINS) step = MINS; if (step > MAXS) step = MAXS; }
+      t += step;
+      if (t > 10) break;
+    }
+    return hit ? t : 10;
+  }
+  function marchV23(px, k, v3) { // adaptiveStepV2.ts:22-124, adaptiveStepV3.ts:22-137
+    let t = 0, prevSDF = 0, prevStep = 0;
+    if (!accelStart()) return 10;
+    for (let i = 0; i < 100; i++) {
+      at(t);
+      const skip = accelStep(t);
+      if (skip === -1) return 10;
+      if (skip > 0) { t += skip; if (t > 10) break; prevSDF = 0; prevStep = 0; continue; }
+      const nw = dist(p, px);
+      iters[px] += 1;
+      if (nw < 0.001) break;
+      if (t > 10) break;
+      if (i === 0 || prevSDF === 0) { t += nw; prevSDF = nw; prevStep = nw; continue; }
+      if (prevStep <= (prevSDF + nw)) { const st = nw * k; t += st; prevSDF = nw; prevStep = st; continue; }
+      if (!v3) { t -= prevStep; t += prevSDF; prevStep = prevSDF; continue; }
+      const orig = t - prevStep;
+      t = orig + prevSDF;
+      at(t);
+      const d3 = dist(p, px);
+      iters[px] += 1;
+      if (prevSDF + nw + d3 >= prevStep) { t = orig + prevStep + nw; prevSDF = nw; prevStep = nw; continue; }
+      prevSDF = d3; prevStep = d3; t += d3;
+    }
+    return t;
+  }
+  function march(px) { // raymarchWorker.ts:49-68
+    switch (algorithm) {
+      case 'fixed-step': return marchFixed(px, stepSize === undefined ? 0.1 : stepSize);
+      case 'adaptive-step': return marchAdaptive(px);
+      case 'adaptive-step-v2': return marchV23(px, overshootFactor === undefined ? 1.2 : overshootFactor, false);
+      case 'adaptive-step-v3': return marchV23(px, overshootFactor === undefined ? 1.2 : overshootFactor, true);
+      default: return marchSphere(px);
+    }
   }
 
   for (let y = y0; y < y1; y++) {
@@ -455,7 +537,7 @@ function cmdRender(cfgPath, outDir) {
   const W = cfg.width, H = cfg.height;
   const y0 = cfg.yStart === undefined ? 0 : cfg.yStart, y1 = cfg.yEnd === undefined ? H : cfg.yEnd;
   const t0 = process.hrtime.bigint();
-  const r = renderTile(S, cam, W, H, y0, y1);
+  const r = renderTile(S, cam, W, H, y0, y1, cfg.algorithm, cfg.overshootFactor, cfg.stepSize);
   const t1 = process.hrtime.bigint();
   const rgba = shade(cfg.shader || 'normal', r.depth, r.normal, r.sdf, r.iters, W, y1 - y0);
   let sumS = 0, sumI = 0, mx = 0, mn = Number.MAX_SAFE_INTEGER;

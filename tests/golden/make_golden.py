@@ -46,6 +46,19 @@ CASES = {
     "P1_random7_360p_octree_rot": dict(preset=1, accel="Octree", width=640, height=360, pitch=0.9, yaw=-2.3,
                                        shader="phong", js="full"),
     "P4_atom_360p_bvh": dict(preset=4, accel="BVH", width=640, height=360, pitch=-1.7, yaw=0.1, shader="normal", js="full"),
+    # the four other marchers
+    "M1_fixed_360p_bvh": dict(preset=3, accel="BVH", width=640, height=360, shader="sdf-heatmap", algorithm="fixed-step",
+                              stepSize=0.05, js="full"),
+    "M2_adaptive_360p_octree": dict(preset=3, accel="Octree", width=640, height=360, shader="iteration-heatmap",
+                                    algorithm="adaptive-step", pitch=0.2, yaw=1.1, js="full"),
+    "M3_v2_360p_bvh_rot": dict(preset=3, accel="BVH", width=640, height=360, shader="phong", algorithm="adaptive-step-v2",
+                               overshootFactor=1.5, pitch=0.3, yaw=0.7, js="full"),
+    "M4_v3_360p_none": dict(preset=1, accel="None", width=640, height=360, shader="normal", algorithm="adaptive-step-v3",
+                            js="full"),
+    "M5_v3_270p_octree10k": dict(synthetic=10000, accel="Octree", width=480, height=270, shader="iteration-heatmap",
+                                 algorithm="adaptive-step-v3", overshootFactor=1.35, js="full"),
+    "M6_fixed_default_270p_none": dict(preset=2, accel="None", width=480, height=270, shader="sdf-heatmap",
+                                       algorithm="fixed-step", js="full"),
 }
 CROP = 64  # crop side, centred
 
@@ -67,7 +80,9 @@ def c_render(cfg, y0=None, y1=None, width=None, height=None):
     for a in range(y0, y1, step):
         bands.append((a, min(y1, a + step)))
     with ThreadPoolExecutor(THREADS) as ex:
-        parts = list(ex.map(lambda b: sc.render(W, H, b[0], b[1]), bands))
+        parts = list(ex.map(lambda b: sc.render(W, H, b[0], b[1], algorithm=cfg.get("algorithm", "sphere-tracer"),
+                                                overshoot_factor=cfg.get("overshootFactor"),
+                                                step_size=cfg.get("stepSize")), bands))
     d, n, s, i = (np.concatenate([p[k] for p in parts]) for k in range(4))
     rgba = O.shade(cfg["shader"], d, n, s, i, W, y1 - y0)
     return d, n, s, i, rgba
@@ -87,6 +102,9 @@ def js_render(cfg, y0=None, y1=None, width=None, height=None):
             j["spheres_file"] = os.path.join(td, "spheres.f64")
         else:
             j["preset"] = cfg["preset"]
+        for k in ("algorithm", "overshootFactor", "stepSize"):
+            if k in cfg:
+                j[k] = cfg[k]
         with open(os.path.join(td, "cfg.json"), "w") as f:
             json.dump(j, f)
         out = subprocess.check_output(["node", os.path.join(ROOT, "oracle", "rm_oracle.js"), "render",

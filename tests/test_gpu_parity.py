@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 NAMES = ("depth", "normal", "sdf", "iters")
 
 
-def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None):
+def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
+               overshoot=None, step=None):
     sc = rm.Scene(accel, ctx=ctx)
     if spheres is not None:
         sc.loadSpheres(spheres[:, :3], spheres[:, 3])
@@ -24,15 +25,16 @@ def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=
     y0, y1 = rows if rows else (0, H)
     n = W * max(0, y1 - y0)
     bufs = (np.zeros(n, np.uint8), np.zeros(3 * n, np.uint8), np.zeros(n, np.uint16), np.zeros(n, np.uint16))
-    rm.SphereTracer().runRaymarcher(sc, *bufs, W, H, 0.0, y0, y1)
+    rm.createRaymarcher(algorithm, overshoot, step).runRaymarcher(sc, *bufs, W, H, 0.0, y0, y1)
     return bufs
 
 
-def cpu_render(oracle, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None):
+def cpu_render(oracle, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
+               overshoot=None, step=None):
     sc = oracle.OracleScene(preset=preset, accel=accel, spheres=spheres)
     sc.set_angles(*ang)
     y0, y1 = rows if rows else (0, H)
-    return sc.render(W, H, y0, y1)
+    return sc.render(W, H, y0, y1, algorithm=algorithm, overshoot_factor=overshoot, step_size=step)
 
 
 def assert_same(got, want, what):
@@ -93,6 +95,20 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
 def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):
     got = gpu_render(rm, gpu_ctx, preset, accel, 200, 150)
     assert_same(got, cpu_render(oracle, preset, accel, 200, 150), "preset %d %s" % (preset, accel))
+
+
+@pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
+@pytest.mark.parametrize("alg,overshoot,step", [("fixed-step", None, None), ("fixed-step", None, 0.03),
+                                                 ("adaptive-step", None, None), ("adaptive-step-v2", None, None),
+                                                 ("adaptive-step-v2", 1.8, None), ("adaptive-step-v3", None, None),
+                                                 ("adaptive-step-v3", 1.05, None)])
+def test_other_marchers(rm, gpu_ctx, oracle, accel, alg, overshoot, step):
+    """The rest of the Algorithm plugin (raymarchWorker.ts:49-68): same accel prologue / skip
+    protocol, different step rule; counters and G-buffers bit-exact against the oracle."""
+    for preset, ang in ((3, (0.2, 0.5)), (1, (0.0, 0.0))):
+        got = gpu_render(rm, gpu_ctx, preset, accel, 220, 140, ang, algorithm=alg, overshoot=overshoot, step=step)
+        want = cpu_render(oracle, preset, accel, 220, 140, ang, algorithm=alg, overshoot=overshoot, step=step)
+        assert_same(got, want, "%s %s preset %d" % (alg, accel, preset))
 
 
 @pytest.mark.parametrize("accel,ang", [("BVH", (0.3, 0.7)), ("Octree", (-0.4, 2.1)), ("BVH", (1.2, -0.3)),
@@ -159,8 +175,6 @@ def test_empty_scene_and_bad_inputs(rm, gpu_ctx, oracle):
         assert_same(got, cpu_render(oracle, None, accel, 40, 30, spheres=empty), "empty scene " + accel)
     sc = rm.Scene("BVH", ctx=gpu_ctx)
     bufs = (np.zeros(16, np.uint8), np.zeros(48, np.uint8), np.zeros(16, np.uint16), np.zeros(16, np.uint16))
-    with pytest.raises(rm.RmUnsupported):  # not native yet: the host keeps its CPU path for these
-        rm.FixedStep(0.05).runRaymarcher(sc, *bufs, 4, 4)
     with pytest.raises(rm.RmUnsupported):
         sc.loadPreset(9)
     sc.camera.pitch = float("nan")
@@ -295,7 +309,8 @@ def test_golden_fixtures_at_baseline_sizes(rm, gpu_ctx, oracle, golden, golden_c
         W, H = cfg["width"], cfg["height"]
         spheres = oracle.synthetic_spheres(cfg["synthetic"]) if "synthetic" in cfg else None
         got = gpu_render(rm, gpu_ctx, cfg.get("preset"), cfg["accel"], W, H, (cfg.get("pitch", 0.0), cfg.get("yaw", 0.0)),
-                         spheres=spheres)
+                         spheres=spheres, algorithm=cfg.get("algorithm", "sphere-tracer"),
+                         overshoot=cfg.get("overshootFactor"), step=cfg.get("stepSize"))
         rgba = np.zeros(4 * W * H, np.uint8)
         rm.createShadingModelFromValue(cfg["shader"], gpu_ctx).shade(rgba, *got, W, H)
         c = g["crop"]

@@ -43,6 +43,8 @@ def test_host_only_context_refuses_to_render(addon):
     dict(preset=3, accel="BVH", width=320, height=200, shader="iteration-heatmap", pitch=0.3, yaw=0.7),
     dict(preset=3, accel="Octree", width=200, height=120, shader="phong", yStart=17, yEnd=93),
     dict(preset=2, accel="BVH", width=160, height=90, shader="sdf-heatmap", algorithm="no-such-marcher"),
+    dict(preset=3, accel="BVH", width=160, height=90, shader="sdf-heatmap", algorithm="adaptive-step-v3", overshootFactor=1.4),
+    dict(preset=3, accel="Octree", width=160, height=90, shader="normal", algorithm="fixed-step"),
 ])
 def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
@@ -53,7 +55,8 @@ def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
     y0, y1 = cfg.get("yStart", 0), cfg.get("yEnd", H)
     sc = oracle.OracleScene(preset=cfg["preset"], accel=cfg["accel"])
     sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0))
-    d, n, s, i = sc.render(W, H, y0, y1)
+    d, n, s, i = sc.render(W, H, y0, y1, algorithm=cfg.get("algorithm", "sphere-tracer"),
+                           overshoot_factor=cfg.get("overshootFactor"), step_size=cfg.get("stepSize"))
     rgba = oracle.shade(cfg["shader"], d, n, s, i, W, y1 - y0)
     for name, arr in (("depth", d), ("normal", n), ("sdf", s), ("iters", i), ("rgba", rgba)):
         got = np.fromfile(str(tmp_path / "out" / (name + ".bin")), dtype=arr.dtype)
@@ -68,7 +71,7 @@ def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
 
 @pytest.mark.gpu
 def test_node_worker_reports_unsupported(addon, tmp_path):
-    cfg = dict(preset=3, accel="BVH", width=16, height=16, shader="normal", algorithm="fixed-step")
+    cfg = dict(preset=7, accel="BVH", width=16, height=16, shader="normal")  # "Cube": a Box primitive
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
     p = subprocess.run([NODE, os.path.join(ROOT, "native", "render_cli.js"), str(tmp_path / "cfg.json"),
                         str(tmp_path / "out")], stdout=subprocess.PIPE)

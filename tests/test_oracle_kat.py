@@ -112,8 +112,6 @@ def test_empty_and_degenerate_inputs(oracle):
     assert d.size == 0
     with pytest.raises(ValueError):
         oracle.OracleScene(preset=7, accel="None")  # box preset: out of scope
-    with pytest.raises(NotImplementedError):
-        sc.render(8, 8, algorithm="fixed-step")
     assert np.array_equal(sc.render(8, 8, algorithm="no-such-marcher")[2], sc.render(8, 8)[2])  # default branch
 
 
@@ -126,7 +124,8 @@ def test_golden_small_cases(oracle, golden):
         spheres = oracle.synthetic_spheres(cfg["synthetic"]) if "synthetic" in cfg else None
         sc = oracle.OracleScene(preset=cfg.get("preset"), accel=cfg["accel"], spheres=spheres)
         sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0))
-        d, n, s, i = sc.render(cfg["width"], cfg["height"])
+        d, n, s, i = sc.render(cfg["width"], cfg["height"], algorithm=cfg.get("algorithm", "sphere-tracer"),
+                               overshoot_factor=cfg.get("overshootFactor"), step_size=cfg.get("stepSize"))
         rgba = oracle.shade(cfg["shader"], d, n, s, i, cfg["width"], cfg["height"])
         for key, arr in zip(("depth", "normal", "sdf", "iters", "rgba"), (d, n, s, i, rgba)):
             assert hashlib.sha256(arr.tobytes()).hexdigest() == g["sha256"][key], (name, key)

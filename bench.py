@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "contiguous"])
     ap.add_argument("--stripe", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--analytics-sweep", action="store_true",
+                    help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
+                         "(main.ts:438-441) and report the per-frame metric series (main.ts:550-566); N = 1 only")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (rm_set_option)")
     args = ap.parse_args()
 
@@ -155,7 +158,11 @@ def main():
         sdf = torch.zeros(W * H, dtype=torch.int16, device=dev)
         iters = torch.zeros(W * H, dtype=torch.int16, device=dev)
 
+        series = []  # analytics sweep: one accumulator per frame, read after the timed region
+
         def step(timed):
+            if args.analytics_sweep:
+                scene.camera.rotateCamera(0, 0.015)  # main.ts:438-441
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -163,6 +170,10 @@ def main():
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
+            if args.analytics_sweep and timed:
+                a = torch.zeros(4, dtype=torch.int64, device=dev)
+                ctx.reduce_counters_enqueue(sdf, iters, a)
+                series.append((scene.camera.yaw, a))
             ctx.reduce_counters_enqueue(sdf, iters, acc)
 
         def finish():
@@ -302,7 +313,13 @@ def main():
                                  W, H, 0.0, shadedBuffer=full["rgba"], shader=wl["shader"])
             torch.cuda.synchronize()
             out["gathered_frame_equals_single_gpu_frame"] = all(bool(torch.equal(asm.frame[s], full[s])) for s in full)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and args.analytics_sweep:
+            out["config"]["camera"] = {"pitch": 0.0, "yaw": "+0.015 rad per frame (analytics sweep)"}
+            out["analytics_series"] = [
+                {"yaw": round(y, 6), "avg_sdf_calls": ctx.decode_acc(a)["total_sdf"] / (W * H),
+                 "avg_iterations": ctx.decode_acc(a)["total_iters"] / (W * H), "max_sdf_calls": ctx.decode_acc(a)["max_sdf"],
+                 "frame_ms": e0.elapsed_time(e1)} for (y, a), (e0, e1) in zip(series, ev_pairs)]
+        if world == 1 and not args.no_cpu_baseline and not args.analytics_sweep:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -345,3 +345,22 @@ def test_full_size_properties(rm, gpu_ctx):
     d = gpu_ctx.reduce_counters(whole[2], whole[3])
     assert d["total_sdf"] == int(whole[2].astype(np.int64).sum()) and d["total_iters"] == int(whole[3].astype(np.int64).sum())
     assert d["max_sdf"] == int(whole[2].max()) and d["min_sdf"] == int(whole[2].min())
+
+
+def test_analytics_sweep_frames(rm, gpu_ctx, oracle):
+    """the Analytics view rotates the camera by 0.015 rad of yaw per frame
+    (main.ts:438-441); every frame of the sweep must match the oracle (host Math.sin/cos path)."""
+    W, H = 160, 90
+    sc = rm.Scene("BVH", ctx=gpu_ctx)
+    sc.loadPreset(3)
+    osc = oracle.OracleScene(preset=3, accel="BVH")
+    yaw = 0.0
+    for frame in range(12):
+        sc.camera.rotateCamera(0, 0.015)
+        yaw += 0.015
+        n = W * H
+        bufs = (np.zeros(n, np.uint8), np.zeros(3 * n, np.uint8), np.zeros(n, np.uint16), np.zeros(n, np.uint16))
+        rm.SphereTracer().runRaymarcher(sc, *bufs, W, H, float(frame))
+        osc.set_angles(0.0, yaw)
+        assert sc.camera.yaw == yaw
+        assert_same(bufs, osc.render(W, H), "sweep frame %d" % frame)

@@ -264,9 +264,13 @@ static inline double vec3_dot(const float *a, const float *b) {
 typedef struct { float min[3], max[3]; } BBox; /* boundingBox.ts:5-12 (vec3.clone -> f32) */
 
 /* primitives/primitive.ts:3-44 + primitives/sphere.ts:4-18 (Sphere only) */
+enum { PRIM_SPHERE = 0, PRIM_BOX = 1, PRIM_TORUS = 2 };
 typedef struct {
     float transform[16]; /* world -> local */
-    double radius;       /* stays a JS double (sphere.ts:5-9) */
+    int type;
+    double radius;       /* Sphere: stays a JS double (sphere.ts:5-9) */
+    float halfSize[3];   /* Box: vec3.clone(halfSize) -> Float32Array (box.ts:8-11) */
+    double majorRadius, minorRadius; /* Torus (torus.ts:8-12) */
 } Prim;
 
 typedef struct BVHNode {
@@ -311,7 +315,30 @@ static void prim_world_position(const Prim *p, float *out) {
 static inline double prim_sdf(const Prim *p, const float *pos) {
     float local[3];
     vec3_transformMat4(local, pos, p->transform);
+    if (p->type == PRIM_BOX) { /* box.ts:13-30 */
+        float q[3], outside[3];
+        for (int i = 0; i < 3; i++) {
+            q[i] = f32(fabs((double)local[i]) - (double)p->halfSize[i]);
+            outside[i] = f32(js_max(q[i], 0));
+        }
+        double outsideDist = vec3_length(outside);
+        double insideDist = js_min(js_max(q[0], js_max(q[1], q[2])), 0);
+        return outsideDist + insideDist;
+    }
+    if (p->type == PRIM_TORUS) { /* torus.ts:14-25 */
+        double x = local[0], y = local[1], z = local[2];
+        double qx = sqrt(x * x + z * z) - p->majorRadius;
+        double qy = y;
+        return sqrt(qx * qx + qy * qy) - p->minorRadius;
+    }
     return vec3_length(local) - p->radius;
+}
+
+/* getLocalBoundingRadius: sphere.ts:16-18, box.ts:32-34, torus.ts:27-29 */
+static double prim_local_radius(const Prim *p) {
+    if (p->type == PRIM_BOX) return vec3_length(p->halfSize);
+    if (p->type == PRIM_TORUS) return p->majorRadius + p->minorRadius;
+    return p->radius;
 }
 
 /* boundingBox.ts:15-21 */
@@ -364,7 +391,7 @@ static void bbox_center(const BBox *b, float *c) {
 static void bbox_fromPrimitive(const Prim *p, BBox *out) {
     float wp[3];
     prim_world_position(p, wp);
-    double localRadius = p->radius;
+    double localRadius = prim_local_radius(p);
     float l2w[16];
     mat4_identity(l2w);
     int ok = mat4_invert(l2w, p->transform);
@@ -720,6 +747,50 @@ static void make_sphere(Prim *p, double x, double y, double z, double radius) {
     p->radius = radius;
 }
 
+/* mat4.fromTranslation + mat4.rotateZ (in place forms have the same arithmetic) */
+static void mat4_rotateZ(float *out, const float *a, double rad) {
+    double s = sin(rad), c = cos(rad);
+    double a00 = a[0], a01 = a[1], a02 = a[2], a03 = a[3];
+    double a10 = a[4], a11 = a[5], a12 = a[6], a13 = a[7];
+    float o[16];
+    memcpy(o, a, sizeof o);
+    o[0] = f32(a00 * c + a10 * s); o[1] = f32(a01 * c + a11 * s); o[2] = f32(a02 * c + a12 * s); o[3] = f32(a03 * c + a13 * s);
+    o[4] = f32(a10 * c - a00 * s); o[5] = f32(a11 * c - a01 * s); o[6] = f32(a12 * c - a02 * s); o[7] = f32(a13 * c - a03 * s);
+    memcpy(out, o, sizeof o);
+}
+
+/* sceneManager.ts:21-37 getTransform; rot == NULL: the fromRotationTranslationScale branch.
+ * `rot` is a gl-matrix vec3 (Float32Array), e.g. vec3.fromValues(-Math.PI/2, 0, 0). */
+static void get_transform(float *worldToLocal, double x, double y, double z, const float *rot) {
+    float model[16];
+    mat4_identity(model);
+    if (rot) {
+        float t[16], u[16];
+        model[12] = f32(x); model[13] = f32(y); model[14] = f32(z); /* mat4.fromTranslation */
+        mat4_rotateX(t, model, rot[0]);
+        mat4_rotateY(u, t, rot[1]);
+        mat4_rotateZ(model, u, rot[2]);
+    } else {
+        double q[4] = {0, 0, 0, 1}, v[3] = {x, y, z}, sc[3] = {1, 1, 1};
+        mat4_fromRTS(model, q, v, sc);
+    }
+    mat4_identity(worldToLocal);
+    mat4_invert(worldToLocal, model);
+}
+
+/* sceneManager.ts:43-49 createBox / createTorus */
+static void make_box(Prim *p, double x, double y, double z, double hx, double hy, double hz, const float *rot) {
+    get_transform(p->transform, x, y, z, rot);
+    p->type = PRIM_BOX;
+    p->halfSize[0] = f32(hx); p->halfSize[1] = f32(hy); p->halfSize[2] = f32(hz);
+}
+static void make_torus(Prim *p, double x, double y, double z, double radius, const float *rot) {
+    get_transform(p->transform, x, y, z, rot);
+    p->type = PRIM_TORUS;
+    p->majorRadius = radius;
+    p->minorRadius = radius / 4;
+}
+
 static ro_scene *scene_alloc(int n, const char *accel) {
     ro_scene *s = (ro_scene *)calloc(1, sizeof *s);
     s->n = n;
@@ -781,8 +852,29 @@ ro_scene *ro_scene_from_preset(int index, const char *accel) {
         for (int i = 0; i < 7; i++) make_sphere(&s->prims[i], v[i][0], v[i][1], v[i][2], v[i][3]);
         break;
     }
+    case 5: { /* "Torus", sceneManager.ts:171-176 */
+        const float rot[3] = {f32(-3.141592653589793 / 2), 0.0f, 0.0f};
+        s = scene_alloc(1, accel);
+        make_torus(&s->prims[0], 0, 0, 0, 1.3, rot);
+        break;
+    }
+    case 7: /* "Cube" */
+        s = scene_alloc(1, accel);
+        make_box(&s->prims[0], 0, 0, 0, 1, 1, 1, NULL);
+        break;
+    case 8: /* "Sphere and Cube" */
+        s = scene_alloc(2, accel);
+        make_sphere(&s->prims[0], -0.7, 0, 0, 0.5);
+        make_box(&s->prims[1], 1, 0, 0, 0.5, 0.5, 0.5, NULL);
+        break;
+    case 9: /* "Pyramid of Boxes" */
+        s = scene_alloc(3, accel);
+        make_box(&s->prims[0], 0, 0.5, 0, 0.9, 0.25, 0.9, NULL);
+        make_box(&s->prims[1], 0, 0, 0, 0.6, 0.25, 0.6, NULL);
+        make_box(&s->prims[2], 0, -0.5, 0, 0.3, 0.25, 0.3, NULL);
+        break;
     default:
-        return NULL;
+        return NULL; /* SDF operators / Mandelbulb: SURVEY 8(f) N4 */
     }
     scene_build_accel(s);
     return s;
@@ -795,6 +887,41 @@ ro_scene *ro_scene_from_spheres(const double *xyz, const double *radii, int n, c
     for (int i = 0; i < n; i++) make_sphere(&s->prims[i], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], radii[i]);
     scene_build_accel(s);
     return s;
+}
+
+/* Build-defined generic entry for tests: n primitives, each described by 11 doubles
+ * {type, x, y, z, rotX, rotY, rotZ (NaN rotX = no rotation argument), p0, p1, p2, unused}:
+ * sphere p0 = radius; box p0..p2 = halfSize; torus p0 = radius (minor = radius / 4). */
+ro_scene *ro_scene_from_prims(const double *desc, int n, const char *accel) {
+    ro_scene *s = scene_alloc(n, accel);
+    for (int i = 0; i < n; i++) {
+        const double *d = desc + 11 * i;
+        float rot[3] = {f32(d[4]), f32(d[5]), f32(d[6])};
+        const float *r = (d[4] != d[4]) ? NULL : rot;
+        int type = (int)d[0];
+        if (type == PRIM_BOX) make_box(&s->prims[i], d[1], d[2], d[3], d[7], d[8], d[9], r);
+        else if (type == PRIM_TORUS) make_torus(&s->prims[i], d[1], d[2], d[3], d[7], r);
+        else {
+            get_transform(s->prims[i].transform, d[1], d[2], d[3], r);
+            s->prims[i].type = PRIM_SPHERE;
+            s->prims[i].radius = d[7];
+        }
+    }
+    scene_build_accel(s);
+    return s;
+}
+
+/* per primitive: type, world->local transform (16 f32), params (3 doubles) -- what the product's
+ * rm_scene_from_prims takes */
+void ro_scene_prims(const ro_scene *s, int *types, float *transforms, double *params) {
+    for (int i = 0; i < s->n; i++) {
+        const Prim *p = &s->prims[i];
+        types[i] = p->type;
+        memcpy(transforms + 16 * i, p->transform, 16 * sizeof(float));
+        if (p->type == PRIM_BOX) { params[3 * i] = p->halfSize[0]; params[3 * i + 1] = p->halfSize[1]; params[3 * i + 2] = p->halfSize[2]; }
+        else if (p->type == PRIM_TORUS) { params[3 * i] = p->majorRadius; params[3 * i + 1] = p->minorRadius; params[3 * i + 2] = 0; }
+        else { params[3 * i] = p->radius; params[3 * i + 1] = 0; params[3 * i + 2] = 0; }
+    }
 }
 
 void ro_scene_free(ro_scene *s) {

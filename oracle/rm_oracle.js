@@ -95,17 +95,35 @@ function cameraMatrix(pitch, yaw) {
 // ---------------------------------------------------------------- scene tables
 // prims: {T: Float32Array(16) world->local, r: double, c: Float32Array(3) world position,
 //         lo/hi: Float32Array(3) padded AABB}
-function makeSphere(x, y, z, r) {
-  const model = m4fromRTS([0, 0, 0, 1], [x, y, z], [1, 1, 1]);
+function m4rotZ(a, rad) { // mat4.rotateZ into a fresh matrix
+  const o = new Float32Array(a), s = Math.sin(rad), c = Math.cos(rad);
+  for (let k = 0; k < 4; k++) { o[k] = a[k] * c + a[4 + k] * s; o[4 + k] = a[4 + k] * c - a[k] * s; }
+  return o;
+}
+
+// desc: [x, y, z, r] (sphere, no rotation argument) or
+//       {type: 'sphere'|'box'|'torus', pos: [x,y,z], rot: Float32Array(3)|undefined, r | half | radius}
+function makePrim(desc) {
+  if (Array.isArray(desc)) desc = { type: 'sphere', pos: [desc[0], desc[1], desc[2]], r: desc[3] };
+  let model;
+  if (desc.rot) { // sceneManager.ts:24-29: fromTranslation, rotateX, rotateY, rotateZ
+    model = m4identity(); model[12] = desc.pos[0]; model[13] = desc.pos[1]; model[14] = desc.pos[2];
+    model = m4rotZ(m4rotY(m4rotX(model, desc.rot[0]), desc.rot[1]), desc.rot[2]);
+  } else model = m4fromRTS([0, 0, 0, 1], desc.pos, [1, 1, 1]);
   const T = m4identity(); m4invert(T, model);
   const back = m4identity(); const ok = m4invert(back, T);
   const c = new Float32Array([back[12], back[13], back[14]]);
   const m = ok ? back : T;
   const sc = Math.max(Math.hypot(m[0], m[1], m[2]), Math.hypot(m[4], m[5], m[6]), Math.hypot(m[8], m[9], m[10]));
-  const pad = r * sc * 1.5;
-  const lo = new Float32Array([c[0] - pad, c[1] - pad, c[2] - pad]);
-  const hi = new Float32Array([c[0] + pad, c[1] + pad, c[2] + pad]);
-  return { T, r, c, lo, hi };
+  const q = { T, c, type: desc.type };
+  let localRadius;
+  if (desc.type === 'box') { q.half = new Float32Array(desc.half); localRadius = Math.hypot(q.half[0], q.half[1], q.half[2]); }
+  else if (desc.type === 'torus') { q.major = desc.radius; q.minor = desc.radius / 4; localRadius = q.major + q.minor; }
+  else { q.r = desc.r; localRadius = q.r; }
+  const pad = localRadius * sc * 1.5;
+  q.lo = new Float32Array([c[0] - pad, c[1] - pad, c[2] - pad]);
+  q.hi = new Float32Array([c[0] + pad, c[1] + pad, c[2] + pad]);
+  return q;
 }
 
 function presetSpheres(index) {
@@ -119,7 +137,12 @@ function presetSpheres(index) {
     const g = 5, sp = 0.6, off = (g - 1) * sp / 2;
     for (let x = 0; x < g; x++) for (let y = 0; y < g; y++) for (let z = 0; z < g; z++) out.push([x * sp - off, y * sp - off, z * sp - off, 0.15]);
   } else if (i === 4) out.push([0, 0, 0, 0.5], [1.2, 0, 0, 0.3], [-1.2, 0, 0, 0.3], [0, 1.2, 0, 0.3], [0, -1.2, 0, 0.3], [0, 0, 1.2, 0.3], [0, 0, -1.2, 0.3]);
-  else throw new Error('preset ' + i + ' needs non-sphere primitives (out of scope)');
+  else if (i === 5) out.push({ type: 'torus', pos: [0, 0, 0], radius: 1.3, rot: new Float32Array([-Math.PI / 2, 0, 0]) });
+  else if (i === 7) out.push({ type: 'box', pos: [0, 0, 0], half: [1, 1, 1] });
+  else if (i === 8) out.push([-0.7, 0, 0, 0.5], { type: 'box', pos: [1, 0, 0], half: [0.5, 0.5, 0.5] });
+  else if (i === 9) out.push({ type: 'box', pos: [0, 0.5, 0], half: [0.9, 0.25, 0.9] }, { type: 'box', pos: [0, 0, 0], half: [0.6, 0.25, 0.6] },
+    { type: 'box', pos: [0, -0.5, 0], half: [0.3, 0.25, 0.3] });
+  else throw new Error('preset ' + i + ' needs SDF operators / Mandelbulb (out of scope)');
   return out;
 }
 
@@ -289,12 +312,22 @@ function sphereSdf(q, p, useSqrt) { // primitive.ts:33-39, sphere.ts:12-14
   const lx = fr((m[0] * x + m[4] * y + m[8] * z + m[12]) / w);
   const ly = fr((m[1] * x + m[5] * y + m[9] * z + m[13]) / w);
   const lz = fr((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
+  if (q.type === 'box') { // box.ts:13-30
+    const e = new Float32Array([Math.abs(lx) - q.half[0], Math.abs(ly) - q.half[1], Math.abs(lz) - q.half[2]]);
+    const out = new Float32Array([Math.max(e[0], 0), Math.max(e[1], 0), Math.max(e[2], 0)]);
+    const od = useSqrt ? Math.sqrt(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) : Math.hypot(out[0], out[1], out[2]);
+    return od + Math.min(Math.max(e[0], Math.max(e[1], e[2])), 0);
+  }
+  if (q.type === 'torus') { // torus.ts:14-25
+    const qx = Math.sqrt(lx * lx + lz * lz) - q.major;
+    return Math.sqrt(qx * qx + ly * ly) - q.minor;
+  }
   const len = useSqrt ? Math.sqrt(lx * lx + ly * ly + lz * lz) : Math.hypot(lx, ly, lz);
   return len - q.r;
 }
 
 function makeScene(spheres, accel, useSqrt) {
-  const prims = spheres.map(s => makeSphere(s[0], s[1], s[2], s[3]));
+  const prims = spheres.map(makePrim);
   const S = { prims, accel, bvh: null, oct: null, useSqrt: !!useSqrt };
   if (accel === 'BVH') S.bvh = buildBVH(prims);
   else if (accel === 'Octree') S.oct = buildOctree(prims);
@@ -531,6 +564,8 @@ function cmdRender(cfgPath, outDir) {
     const f = new Float64Array(raw.buffer, raw.byteOffset, raw.byteLength / 8);
     spheres = [];
     for (let i = 0; i + 3 < f.length; i += 4) spheres.push([f[i], f[i + 1], f[i + 2], f[i + 3]]);
+  } else if (cfg.prims) {
+    spheres = cfg.prims.map(d => ({ type: d.type, pos: d.pos, rot: d.rot ? new Float32Array(d.rot) : undefined, r: d.r, half: d.half, radius: d.radius }));
   } else spheres = presetSpheres(cfg.preset);
   const S = makeScene(spheres, cfg.accel, cfg.length_sqrt);
   const cam = cameraMatrix(cfg.pitch || 0, cfg.yaw || 0);

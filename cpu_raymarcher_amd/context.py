@@ -72,6 +72,18 @@ class Context:
             raise ValueError("centers and radii differ in length")
         N.check(self._h, N.lib().rm_scene_from_spheres(self._h, _ptr(c), _ptr(r), len(r), int(accel)))
 
+    def scene_from_prims(self, prims, accel):
+        """prims: iterable of (type, world_to_local[16], params[<=3]); type 0 sphere, 1 box, 2 torus."""
+        prims = list(prims)
+        arr = (N.rm_prim * max(1, len(prims)))()
+        for i, (t, m, par) in enumerate(prims):
+            arr[i].type = int(t)
+            for k in range(16):
+                arr[i].world_to_local[k] = float(m[k])
+            for k in range(3):
+                arr[i].params[k] = float(par[k]) if k < len(par) else 0.0
+        N.check(self._h, N.lib().rm_scene_from_prims(self._h, arr, len(prims), int(accel)))
+
     def scene_info(self):
         info = N.rm_scene_info()
         N.check(self._h, N.lib().rm_scene_get_info(self._h, C.byref(info)))
@@ -161,6 +173,16 @@ def _selftest_fastdiv(self, seed, n):
 
 
 Context.selftest_fastdiv = _selftest_fastdiv
+
+
+def make_transform(x, y, z, rotation=None):
+    """SceneManager.getTransform (sceneManager.ts:21-37) -> world->local float32[16]."""
+    out = np.zeros(16, np.float32)
+    rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.float32)
+    rc = N.lib().rm_make_transform(float(x), float(y), float(z), _ptr(rot), _ptr(out))
+    if rc != N.RM_OK:
+        raise N.RmError(rc, "rm_make_transform")
+    return out
 
 
 def camera_from_angles(pitch, yaw):

@@ -31,6 +31,7 @@ struct DeviceScene {
     uint16_t *pq_list = nullptr;
     uint32_t *nn_cells = nullptr;
     uint16_t *nn_list = nullptr;
+    RmPrim *prims = nullptr;
 };
 
 }  // namespace
@@ -50,6 +51,8 @@ struct rm_ctx {
     bool have_uploaded = false;  // sphere list kept for accel changes by later jobs
     std::vector<float> up_centers;
     std::vector<double> up_radii;
+    std::vector<rmh::PrimDesc> up_prims;  // when the uploaded scene came from rm_scene_from_prims
+    bool up_general = false;
 
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -104,6 +107,7 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.pq_list);
     (void)hipFree(d.nn_cells);
     (void)hipFree(d.nn_list);
+    (void)hipFree(d.prims);
     d = DeviceScene();
 }
 
@@ -132,6 +136,7 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.pq_list, &ctx->dev.pq_list))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.nn_cells, &ctx->dev.nn_cells))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.nn_list, &ctx->dev.nn_list))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.prims, &ctx->dev.prims))) return rc;
     return RM_OK;
 }
 
@@ -150,6 +155,25 @@ int set_scene(rm_ctx *ctx, const float *centers, const double *radii, int n, int
     return upload_scene(ctx);
 }
 
+int set_scene_general(rm_ctx *ctx, const rmh::PrimDesc *prims, int n, int accel, bool uploaded, int preset) {
+    std::string err;
+    rmh::HostScene hs;
+    if (!rmh::build_scene_general(hs, prims, n, accel, err)) {
+        const bool unsupported = err.find("BVH leaf") != std::string::npos;
+        return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
+    }
+    hs.preset = preset;
+    ctx->host = std::move(hs);
+    ctx->have_scene = true;
+    ctx->scene_is_uploaded = uploaded;
+    ctx->scene_preset = preset;
+    return upload_scene(ctx);
+}
+
+int scene_n_prims(const rm_ctx *ctx) {
+    return static_cast<int>(ctx->host.general ? ctx->host.prims.size() : ctx->host.spheres.size());
+}
+
 int clamp_preset(int idx) { return idx < 0 ? 0 : (idx > rmh::kPresetCount - 1 ? rmh::kPresetCount - 1 : idx); }
 int norm_accel(int a) { return (a == RM_ACCEL_OCTREE || a == RM_ACCEL_BVH) ? a : RM_ACCEL_NONE; }
 
@@ -159,6 +183,9 @@ int ensure_scene(rm_ctx *ctx, int32_t preset_index, int32_t accel_in) {
     if (preset_index == RM_SCENE_UPLOADED) {
         if (!ctx->have_uploaded) return fail(ctx, RM_E_NO_SCENE, "no scene uploaded with rm_scene_from_spheres");
         if (ctx->have_scene && ctx->scene_is_uploaded && ctx->host.accel == accel) return RM_OK;
+        if (ctx->up_general)
+            return set_scene_general(ctx, ctx->up_prims.data(), static_cast<int>(ctx->up_prims.size()), accel, true,
+                                     RM_SCENE_UPLOADED);
         return set_scene(ctx, ctx->up_centers.data(), ctx->up_radii.data(), static_cast<int>(ctx->up_radii.size()),
                          accel, true, RM_SCENE_UPLOADED);
     }
@@ -167,10 +194,13 @@ int ensure_scene(rm_ctx *ctx, int32_t preset_index, int32_t accel_in) {
         return RM_OK;
     std::vector<float> c;
     std::vector<double> r;
-    if (!rmh::preset_spheres(preset, c, r))
-        return fail(ctx, RM_E_UNSUPPORTED, "scene preset " + std::to_string(preset) +
-                                               " uses non-sphere primitives or SDF operators (not on the native path)");
-    return set_scene(ctx, c.data(), r.data(), static_cast<int>(r.size()), accel, false, preset);
+    if (rmh::preset_spheres(preset, c, r))
+        return set_scene(ctx, c.data(), r.data(), static_cast<int>(r.size()), accel, false, preset);
+    std::vector<rmh::PrimDesc> prims;  // torus / box presets: general primitive records
+    if (rmh::preset_prims(preset, prims))
+        return set_scene_general(ctx, prims.data(), static_cast<int>(prims.size()), accel, false, preset);
+    return fail(ctx, RM_E_UNSUPPORTED, "scene preset " + std::to_string(preset) +
+                                           " uses SDF operators or the Mandelbulb (not on the native path)");
 }
 
 int ensure_scratch(rm_ctx *ctx, size_t bytes) {
@@ -217,7 +247,9 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
         p.origin_d[k] = p.origin[k];
         p.light_d[k] = p.light[k];
     }
-    p.n_prims = static_cast<int32_t>(ctx->host.spheres.size());
+    p.n_prims = scene_n_prims(ctx);
+    p.general = ctx->host.general ? 1 : 0;
+    p.prims = ctx->dev.prims;
     p.accel = ctx->host.accel;
     p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
     p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());
@@ -227,6 +259,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.variant = static_cast<int32_t>(ctx->opt_kernel);
     if (p.variant == 0) p.variant = ctx->host.accel == RM_ACCEL_OCTREE ? 1 : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
+    if (ctx->host.general) p.variant = 1;                    // so do boxes, tori and rotated primitives
     p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
     p.coop = static_cast<int32_t>(ctx->opt_coop);
     p.bvh_prim_count = static_cast<int32_t>(ctx->host.bvh_prims.size());
@@ -358,7 +391,34 @@ int rm_scene_from_spheres(rm_ctx *ctx, const float *centers_xyz, const double *r
     if (rc) return rc;
     ctx->up_centers.assign(centers_xyz, centers_xyz + 3 * static_cast<size_t>(n));
     ctx->up_radii.assign(radii, radii + n);
+    ctx->up_general = false;
     ctx->have_uploaded = true;
+    return RM_OK;
+}
+
+int rm_scene_from_prims(rm_ctx *ctx, const rm_prim *prims, int32_t n, int32_t accel) {
+    if (!ctx) return RM_E_INVALID;
+    if (n < 0 || (n > 0 && !prims)) return fail(ctx, RM_E_INVALID, "bad primitive list");
+    std::vector<rmh::PrimDesc> d(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        d[i].type = prims[i].type;
+        std::memcpy(d[i].m, prims[i].world_to_local, sizeof d[i].m);
+        for (int k = 0; k < 3; ++k) d[i].params[k] = prims[i].params[k];
+    }
+    int rc = set_scene_general(ctx, d.data(), n, norm_accel(accel), true, RM_SCENE_UPLOADED);
+    if (rc) return rc;
+    ctx->up_prims = std::move(d);
+    ctx->up_general = true;
+    ctx->have_uploaded = true;
+    return RM_OK;
+}
+
+int rm_make_transform(double x, double y, double z, const float *rotation_xyz, float *world_to_local16) {
+    if (!world_to_local16 || !std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return RM_E_INVALID;
+    if (rotation_xyz)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(rotation_xyz[k])) return RM_E_INVALID;
+    rmh::make_transform(x, y, z, rotation_xyz, world_to_local16);
     return RM_OK;
 }
 
@@ -367,7 +427,7 @@ int rm_scene_get_info(const rm_ctx *ctx, rm_scene_info *out) {
     if (!ctx->have_scene) return RM_E_NO_SCENE;
     std::memset(out, 0, sizeof *out);
     const rmh::HostScene &h = ctx->host;
-    out->n_prims = static_cast<int32_t>(h.spheres.size());
+    out->n_prims = scene_n_prims(ctx);
     out->accel = h.accel;
     out->preset_index = ctx->scene_preset;
     out->bvh_nodes = static_cast<int32_t>(h.bvh.size());
@@ -584,7 +644,9 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     char *base = static_cast<char *>(ctx->scratch);
     RmRenderParams p;
     std::memset(&p, 0, sizeof p);
-    p.n_prims = static_cast<int32_t>(ctx->host.spheres.size());
+    p.n_prims = scene_n_prims(ctx);
+    p.general = ctx->host.general ? 1 : 0;
+    p.prims = ctx->dev.prims;
     p.accel = ctx->host.accel;
     p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
     p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());

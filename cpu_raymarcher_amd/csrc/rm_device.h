@@ -149,6 +149,33 @@ __device__ __forceinline__ double prims_min(const RmSphere *spheres, const doubl
     return closest;
 }
 
+// Primitive.sdf (primitive.ts:33-39) with the full vec3.transformMat4 (w = w || 1.0), then
+// Sphere / Box / Torus .localSdf (sphere.ts:12-14, box.ts:13-30, torus.ts:14-25).
+__device__ __forceinline__ double prim_sdf_general(const RmPrim &q, const Vec3f &p) {
+    const double x = p.x, y = p.y, z = p.z;
+    double w = q.m[3] * x + q.m[7] * y + q.m[11] * z + q.m[15];
+    if (!(w != 0.0)) w = 1.0;  // 0, -0 and NaN are falsy
+    const float lx = to_f32((q.m[0] * x + q.m[4] * y + q.m[8] * z + q.m[12]) / w);
+    const float ly = to_f32((q.m[1] * x + q.m[5] * y + q.m[9] * z + q.m[13]) / w);
+    const float lz = to_f32((q.m[2] * x + q.m[6] * y + q.m[10] * z + q.m[14]) / w);
+    if (q.type == 1) {
+        const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - static_cast<double>(q.half[0]));
+        const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - static_cast<double>(q.half[1]));
+        const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - static_cast<double>(q.half[2]));
+        const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;  // Math.max(q, 0)
+        const double outside = hypot3(o0, o1, o2);
+        const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);  // Math.max(q0, Math.max(q1, q2))
+        const double inside = big < 0.f ? static_cast<double>(big) : 0.0;       // Math.min(., 0)
+        return outside + inside;
+    }
+    if (q.type == 2) {
+        const double dx = lx, dy = ly, dz = lz;
+        const double qx = __builtin_sqrt(dx * dx + dz * dz) - q.a;
+        return __builtin_sqrt(qx * qx + dy * dy) - q.b;
+    }
+    return hypot3(lx, ly, lz) - q.a;
+}
+
 // BoundingBox.contains (boundingBox.ts:15-21)
 __device__ __forceinline__ bool box_contains(const float lo[3], const float hi[3], const Vec3f &p) {
     return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];

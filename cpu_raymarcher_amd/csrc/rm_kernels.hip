@@ -27,16 +27,32 @@ using namespace rmd;
 
 // ------------------------------------------------------------------ Scene.getDistance
 
+// min over a primitive list for either scene representation
+// GEN is a compile-time property of the kernel instantiation: a run-time `if (P.general)` in
+// front of the sphere loop changed the results of render_kernel<0, true> (lane-grouping
+// dependent wrong normals with hipcc 7.2), so the two representations never share a function body.
+template <bool GEN>
+__device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_t *ids, int n, const Vec3f &p,
+                                           double closest) {
+    if (GEN) {
+        for (int k = 0; k < n; ++k) closest = min_dist(prim_sdf_general(P.prims[ids ? ids[k] : k], p), closest);
+        return closest;
+    }
+    return prims_min<false>(P.spheres, P.radii, ids, n, p, closest, P.filter != 0);
+}
+
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
+template <bool GEN>
 __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
-    closest = prims_min<false>(P.spheres, P.radii, static_cast<const int32_t *>(nullptr), P.n_prims, p, closest, P.filter != 0);
+    closest = list_min<GEN>(P, nullptr, P.n_prims, p, closest);
     count += static_cast<uint32_t>(P.n_prims);
     return closest;
 }
 
 // scene.ts:167-181 with BVH.getPrimitivesAt (bvh.ts:95-121): union of the primitives of
 // every leaf whose box contains p (a primitive lives in exactly one leaf), else all.
+template <bool GEN>
 __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
@@ -53,11 +69,11 @@ __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t
             continue;
         }
         const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
-        closest = prims_min<false>(P.spheres, P.radii, P.bvh_prims + first, cnt, p, closest, P.filter != 0);
+        closest = list_min<GEN>(P, P.bvh_prims + first, cnt, p, closest);
         found += static_cast<uint32_t>(cnt);
         i = node.skip;
     }
-    if (found == 0) return all_prims_distance(P, p, count);
+    if (found == 0) return all_prims_distance<GEN>(P, p, count);
     count += found;
     return closest;
 }
@@ -78,13 +94,13 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
 }
 
 // scene.ts:148-166 given the node findNode returned
+template <bool GEN>
 __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec3f &p, uint32_t &count) {
-    if (node < 0) return all_prims_distance(P, p, count);  // outside the cube: scene.ts:166,183-189
+    if (node < 0) return all_prims_distance<GEN>(P, p, count);  // outside the cube: scene.ts:166,183-189
     const RmOctNode nd = P.oct[node];
     double closest = RM_MAX_DIST;
     if (nd.prim_count > 0) {
-        closest = prims_min<false>(P.spheres, P.radii, P.oct_prims + nd.prim_first, nd.prim_count, p, closest,
-                                   P.filter != 0);
+        closest = list_min<GEN>(P, P.oct_prims + nd.prim_first, nd.prim_count, p, closest);
         count += static_cast<uint32_t>(nd.prim_count);
     } else if (nd.is_empty) {
         closest = min_dist(nd.min_distance * 0.99, closest);  // Math.min(closest, minDistance * safety)
@@ -92,11 +108,11 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
     return closest;
 }
 
-template <int ACCEL>
+template <int ACCEL, bool GEN>
 __device__ __forceinline__ double scene_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
-    if (ACCEL == 2) return bvh_distance(P, p, count);
-    if (ACCEL == 1) return oct_node_distance(P, oct_find(P, p), p, count);
-    return all_prims_distance(P, p, count);
+    if (ACCEL == 2) return bvh_distance<GEN>(P, p, count);
+    if (ACCEL == 1) return oct_node_distance<GEN>(P, oct_find(P, p), p, count);
+    return all_prims_distance<GEN>(P, p, count);
 }
 
 // ------------------------------------------------------------------ BVH ray intervals
@@ -139,7 +155,7 @@ __device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, double 
 
 // ------------------------------------------------------------------ the render kernel
 
-template <int ACCEL>
+template <int ACCEL, bool GEN>
 __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, double depth, uint32_t &count,
                                    uint8_t nb[3]) {
     // raymarcher.ts:94-105
@@ -150,16 +166,16 @@ __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, doub
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (!(depth >= RM_MAX_DIST)) {
         // raymarcher.ts:123-135 getNormal
-        const double d0 = scene_distance<ACCEL>(P, hit, count);
+        const double d0 = scene_distance<ACCEL, GEN>(P, hit, count);
         Vec3f q = hit;
         q.x = to_f32(static_cast<double>(hit.x) - 0.01);
-        nx = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        nx = to_f32(d0 - scene_distance<ACCEL, GEN>(P, q, count));
         q = hit;
         q.y = to_f32(static_cast<double>(hit.y) - 0.01);
-        ny = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        ny = to_f32(d0 - scene_distance<ACCEL, GEN>(P, q, count));
         q = hit;
         q.z = to_f32(static_cast<double>(hit.z) - 0.01);
-        nz = to_f32(d0 - scene_distance<ACCEL>(P, q, count));
+        nz = to_f32(d0 - scene_distance<ACCEL, GEN>(P, q, count));
         double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
         if (len > 0) len = 1 / __builtin_sqrt(len);
         nx = to_f32(nx * len);
@@ -173,7 +189,7 @@ __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, doub
 }
 
 // SphereTracer.rayMarch (sphereTracer.ts:15-83)
-template <int ACCEL>
+template <int ACCEL, bool GEN>
 __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
     double t = 0.0;
     Interval cur;
@@ -216,8 +232,8 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
             }
         }
         double dist;
-        if (ACCEL == 1) dist = oct_node_distance(P, onode, p, count);
-        else dist = scene_distance<ACCEL>(P, p, count);
+        if (ACCEL == 1) dist = oct_node_distance<GEN>(P, onode, p, count);
+        else dist = scene_distance<ACCEL, GEN>(P, p, count);
         t += dist;
         iters += 1;
         if (dist < RM_EPSILON) break;
@@ -232,7 +248,7 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
 //   2 AdaptiveStep    adaptiveStep.ts:22-105    MAX_STEPS 200, step = clamp(0.8 d, 0.025, 0.5) or 0.01 near
 //   3 AdaptiveStepV2  adaptiveStepV2.ts:22-124  overshoot by overshootFactor, step back when spheres do not overlap
 //   4 AdaptiveStepV3  adaptiveStepV3.ts:22-137  as V2 plus the "bridging" third evaluation
-template <int ACCEL>
+template <int ACCEL, bool GEN>
 __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
     const int alg = P.algorithm;
     const int max_steps = (alg == 1 || alg == 2) ? 200 : 100;
@@ -271,7 +287,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
             prevStep = 0.0;
             continue;
         }
-        const double dist = ACCEL == 1 ? oct_node_distance(P, onode, p, count) : scene_distance<ACCEL>(P, p, count);
+        const double dist = ACCEL == 1 ? oct_node_distance<GEN>(P, onode, p, count) : scene_distance<ACCEL, GEN>(P, p, count);
         iters += 1;
         if (alg == 1 || alg == 2) {
             if (dist < RM_EPSILON) {
@@ -316,7 +332,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
         const double originalPos = t - prevStep;
         t = originalPos + prevSDF;
         p = point_at(ray, t);
-        const double d3 = scene_distance<ACCEL>(P, p, count);
+        const double d3 = scene_distance<ACCEL, GEN>(P, p, count);
         iters += 1;
         if (prevSDF + dist + d3 >= prevStep) {
             t = originalPos + prevStep + dist;
@@ -332,7 +348,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     return t;
 }
 
-template <int ACCEL, bool OTHER>
+template <int ACCEL, bool OTHER, bool GEN>
 __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     // wave tile: tile_w x (64 / tile_w); four waves stacked vertically per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -367,9 +383,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     ray.od[2] = P.origin_d[2];
 
     uint32_t count = 0, iters = 0;
-    const double depth = OTHER ? ray_march_other<ACCEL>(P, ray, count, iters) : ray_march<ACCEL>(P, ray, count, iters);
+    const double depth = OTHER ? ray_march_other<ACCEL, GEN>(P, ray, count, iters) : ray_march<ACCEL, GEN>(P, ray, count, iters);
     uint8_t nb[3];
-    normal_and_store<ACCEL>(P, ray, depth, count, nb);
+    normal_and_store<ACCEL, GEN>(P, ray, depth, count, nb);
     const uint8_t db = u8clamp(depth);
     const uint16_t c16 = static_cast<uint16_t>(count & 0xFFFFu);  // Uint16Array += wraps
     const uint16_t i16 = static_cast<uint16_t>(iters & 0xFFFFu);
@@ -473,14 +489,14 @@ __global__ void reduce_init_kernel(RmDiagDevice *acc) {
     acc->pad = 0;
 }
 
-template <int ACCEL>
+template <int ACCEL, bool GEN>
 __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
                                                        uint32_t *count) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (i >= n) return;
     Vec3f p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     uint32_t c = 0;
-    dist[i] = scene_distance<ACCEL>(P, p, c);
+    dist[i] = scene_distance<ACCEL, GEN>(P, p, c);
     count[i] = c;
 }
 
@@ -547,12 +563,14 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
-#define RM_V1(A, O) hipLaunchKernelGGL((render_kernel<A, O>), grid, block, 0, stream, p)
-    if (p.algorithm == 0) {
-        if (p.accel == 2) RM_V1(2, false); else if (p.accel == 1) RM_V1(1, false); else RM_V1(0, false);
+#define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, 0, stream, p)
+#define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G); else if (p.accel == 1) RM_V1(1, O, G); else RM_V1(0, O, G); }
+    if (p.general) {
+        if (p.algorithm == 0) RM_V1A(false, true) else RM_V1A(true, true)
     } else {
-        if (p.accel == 2) RM_V1(2, true); else if (p.accel == 1) RM_V1(1, true); else RM_V1(0, true);
+        if (p.algorithm == 0) RM_V1A(false, false) else RM_V1A(true, false)
     }
+#undef RM_V1A
 #undef RM_V1
     return hipGetLastError();
 }
@@ -586,9 +604,10 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
                               hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
-    if (p.accel == 2) hipLaunchKernelGGL(distance_kernel<2>, grid, block, 0, stream, p, points, n, dist, count);
-    else if (p.accel == 1) hipLaunchKernelGGL(distance_kernel<1>, grid, block, 0, stream, p, points, n, dist, count);
-    else hipLaunchKernelGGL(distance_kernel<0>, grid, block, 0, stream, p, points, n, dist, count);
+#define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, 0, stream, p, points, n, dist, count)
+    if (p.general) { if (p.accel == 2) RM_DK(2, true); else if (p.accel == 1) RM_DK(1, true); else RM_DK(0, true); }
+    else { if (p.accel == 2) RM_DK(2, false); else if (p.accel == 1) RM_DK(1, false); else RM_DK(0, false); }
+#undef RM_DK
     return hipGetLastError();
 }
 

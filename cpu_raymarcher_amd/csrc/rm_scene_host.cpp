@@ -155,8 +155,7 @@ struct BvhBuilder {
         // bvh.ts:66-70: stable sort by world position on that axis (centre, f32)
         std::vector<int32_t> order(ids);
         std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-            const float ca = axis == 0 ? s.spheres[a].cx : axis == 1 ? s.spheres[a].cy : s.spheres[a].cz;
-            const float cb = axis == 0 ? s.spheres[b].cx : axis == 1 ? s.spheres[b].cy : s.spheres[b].cz;
+            const float ca = s.world_pos[3 * a + axis], cb = s.world_pos[3 * b + axis];
             return double(ca) - double(cb) < 0.0;
         });
         const int mid = n / 2;  // bvh.ts:73
@@ -328,7 +327,7 @@ struct OctBuilder {
         std::memcpy(b.lo, node.lo, sizeof b.lo);
         std::memcpy(b.hi, node.hi, sizeof b.hi);
         double best = std::numeric_limits<double>::infinity();
-        const int n = static_cast<int>(s.spheres.size());
+        const int n = static_cast<int>(s.prim_lo.size() / 3);
         for (int i = 0; i < n; ++i) {
             const double d = box_gap(b, &s.prim_lo[3 * i], &s.prim_hi[3 * i]);
             if (d < best) best = d;
@@ -433,6 +432,34 @@ bool preset_spheres(int index, std::vector<float> &centers, std::vector<double> 
     }
 }
 
+// BVH / Octree over the padded primitive boxes already in s.prim_lo / prim_hi
+static bool build_accel(HostScene &s, int n, std::string &err) {
+    std::vector<int32_t> all(n);
+    std::iota(all.begin(), all.end(), 0);
+    if (s.accel == 2) {
+        const Box root = bounds_of(s, all.data(), n);  // bvh.ts:38-41 (ctor bounds arg ignored)
+        BvhBuilder b{s, err};
+        b.emit(all, root, 0);
+        if (!b.ok) return false;
+        std::memcpy(s.root_min, root.lo, sizeof root.lo);
+        std::memcpy(s.root_max, root.hi, sizeof root.hi);
+        if (!s.general) build_point_query_grid(s);
+    } else if (s.accel == 1) {
+        Box root;  // scene.ts:81-85
+        for (int k = 0; k < 3; ++k) {
+            root.lo[k] = -10.0f;
+            root.hi[k] = 10.0f;
+        }
+        s.oct.resize(1);
+        OctBuilder b{s};
+        b.fill(0, all, root, 0);
+        b.mark(0);
+        std::memcpy(s.root_min, root.lo, sizeof root.lo);
+        std::memcpy(s.root_max, root.hi, sizeof root.hi);
+    }
+    return true;
+}
+
 bool build_scene(HostScene &s, const float *centers, const double *radii, int n, int accel,
                  std::string &err) {
     if (n < 0 || (n > 0 && (!centers || !radii))) {
@@ -463,30 +490,173 @@ bool build_scene(HostScene &s, const float *centers, const double *radii, int n,
             s.prim_hi[3 * i + k] = to_f32(double(centers[3 * i + k]) + pad);
         }
     }
-    std::vector<int32_t> all(n);
-    std::iota(all.begin(), all.end(), 0);
-    if (s.accel == 2) {
-        const Box root = bounds_of(s, all.data(), n);  // bvh.ts:38-41 (ctor bounds arg ignored)
-        BvhBuilder b{s, err};
-        b.emit(all, root, 0);
-        if (!b.ok) return false;
-        std::memcpy(s.root_min, root.lo, sizeof root.lo);
-        std::memcpy(s.root_max, root.hi, sizeof root.hi);
-        build_point_query_grid(s);
-    } else if (s.accel == 1) {
-        Box root;  // scene.ts:81-85
-        for (int k = 0; k < 3; ++k) {
-            root.lo[k] = -10.0f;
-            root.hi[k] = 10.0f;
-        }
-        s.oct.resize(1);
-        OctBuilder b{s};
-        b.fill(0, all, root, 0);
-        b.mark(0);
-        std::memcpy(s.root_min, root.lo, sizeof root.lo);
-        std::memcpy(s.root_max, root.hi, sizeof root.hi);
-    }
+    s.world_pos.assign(centers, centers + 3 * size_t(n));
+    return build_accel(s, n, err);
+}
+
+// ---- general primitives -----------------------------------------------------------------------
+
+namespace {
+
+// mat4.invert (gl-matrix 3.x cofactor form); false when the determinant is falsy
+bool invert4(const float a[16], float out[16]) {
+    const double a00 = a[0], a01 = a[1], a02 = a[2], a03 = a[3], a10 = a[4], a11 = a[5], a12 = a[6], a13 = a[7];
+    const double a20 = a[8], a21 = a[9], a22 = a[10], a23 = a[11], a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+    const double b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10, b02 = a00 * a13 - a03 * a10;
+    const double b03 = a01 * a12 - a02 * a11, b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
+    const double b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30, b08 = a20 * a33 - a23 * a30;
+    const double b09 = a21 * a32 - a22 * a31, b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
+    double det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+    if (!(det != 0.0)) return false;
+    det = 1.0 / det;
+    float o[16];
+    o[0] = to_f32((a11 * b11 - a12 * b10 + a13 * b09) * det);
+    o[1] = to_f32((a02 * b10 - a01 * b11 - a03 * b09) * det);
+    o[2] = to_f32((a31 * b05 - a32 * b04 + a33 * b03) * det);
+    o[3] = to_f32((a22 * b04 - a21 * b05 - a23 * b03) * det);
+    o[4] = to_f32((a12 * b08 - a10 * b11 - a13 * b07) * det);
+    o[5] = to_f32((a00 * b11 - a02 * b08 + a03 * b07) * det);
+    o[6] = to_f32((a32 * b02 - a30 * b05 - a33 * b01) * det);
+    o[7] = to_f32((a20 * b05 - a22 * b02 + a23 * b01) * det);
+    o[8] = to_f32((a10 * b10 - a11 * b08 + a13 * b06) * det);
+    o[9] = to_f32((a01 * b08 - a00 * b10 - a03 * b06) * det);
+    o[10] = to_f32((a30 * b04 - a31 * b02 + a33 * b00) * det);
+    o[11] = to_f32((a21 * b02 - a20 * b04 - a23 * b00) * det);
+    o[12] = to_f32((a11 * b07 - a10 * b09 - a12 * b06) * det);
+    o[13] = to_f32((a00 * b09 - a01 * b07 + a02 * b06) * det);
+    o[14] = to_f32((a31 * b01 - a30 * b03 - a32 * b00) * det);
+    o[15] = to_f32((a20 * b03 - a21 * b01 + a22 * b00) * det);
+    std::memcpy(out, o, sizeof o);
     return true;
+}
+
+// mat4.rotateZ (same arithmetic in place or not)
+Mat4 rotate_z(const Mat4 &a, double rad) {
+    const double s = std::sin(rad), c = std::cos(rad);
+    Mat4 r = a;
+    for (int k = 0; k < 4; ++k) {
+        const double row0 = a.m[k], row1 = a.m[4 + k];
+        r.m[k] = to_f32(row0 * c + row1 * s);
+        r.m[4 + k] = to_f32(row1 * c - row0 * s);
+    }
+    return r;
+}
+
+}  // namespace
+
+void make_transform(double x, double y, double z, const float *rot, float out16[16]) {
+    Mat4 model = Mat4::identity();
+    model.m[12] = to_f32(x);  // fromTranslation / fromRotationTranslationScale(identity quat, v, 1)
+    model.m[13] = to_f32(y);
+    model.m[14] = to_f32(z);
+    if (rot) model = rotate_z(rotate_y(rotate_x(model, rot[0]), rot[1]), rot[2]);  // sceneManager.ts:26-29
+    Mat4 inv = Mat4::identity();
+    invert4(model.m, inv.m);  // sceneManager.ts:34-35
+    std::memcpy(out16, inv.m, sizeof inv.m);
+}
+
+bool preset_prims(int index, std::vector<PrimDesc> &out) {
+    out.clear();
+    index = std::max(0, std::min(index, kPresetCount - 1));
+    auto add = [&](int type, double x, double y, double z, const float *rot, double p0, double p1, double p2) {
+        PrimDesc d;
+        d.type = type;
+        make_transform(x, y, z, rot, d.m);
+        d.params[0] = p0;
+        d.params[1] = p1;
+        d.params[2] = p2;
+        out.push_back(d);
+    };
+    if (index <= 4) {
+        std::vector<float> c;
+        std::vector<double> r;
+        preset_spheres(index, c, r);
+        for (size_t i = 0; i < r.size(); ++i) add(0, c[3 * i], c[3 * i + 1], c[3 * i + 2], nullptr, r[i], 0, 0);
+        return true;
+    }
+    switch (index) {
+        case 5: {  // "Torus": createTorus(0,0,0, 1.3, vec3.fromValues(-Math.PI/2, 0, 0)), minor = radius / 4
+            const float rot[3] = {to_f32(-3.141592653589793 / 2), 0.0f, 0.0f};
+            add(2, 0, 0, 0, rot, 1.3, 1.3 / 4, 0);
+            return true;
+        }
+        case 7:  // "Cube"
+            add(1, 0, 0, 0, nullptr, 1, 1, 1);
+            return true;
+        case 8:  // "Sphere and Cube"
+            add(0, -0.7, 0, 0, nullptr, 0.5, 0, 0);
+            add(1, 1, 0, 0, nullptr, 0.5, 0.5, 0.5);
+            return true;
+        case 9:  // "Pyramid of Boxes"
+            add(1, 0, 0.5, 0, nullptr, 0.9, 0.25, 0.9);
+            add(1, 0, 0, 0, nullptr, 0.6, 0.25, 0.6);
+            add(1, 0, -0.5, 0, nullptr, 0.3, 0.25, 0.3);
+            return true;
+        default:
+            return false;  // Round / SmoothUnion / Twist / Repetition / Mandelbulb ...: SURVEY 8(f) N4
+    }
+}
+
+bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, std::string &err) {
+    if (n < 0 || (n > 0 && !prims)) {
+        err = "bad primitive list";
+        return false;
+    }
+    s = HostScene();
+    s.accel = (accel == 1 || accel == 2) ? accel : 0;
+    s.general = true;
+    s.prims.resize(n);
+    s.prim_lo.resize(3 * size_t(n));
+    s.prim_hi.resize(3 * size_t(n));
+    s.world_pos.resize(3 * size_t(n));
+    for (int i = 0; i < n; ++i) {
+        const PrimDesc &d = prims[i];
+        if (d.type < 0 || d.type > 2) {
+            err = "unknown primitive type";
+            return false;
+        }
+        for (int k = 0; k < 16; ++k)
+            if (!std::isfinite(d.m[k])) {
+                err = "non-finite transform";
+                return false;
+            }
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(d.params[k])) {
+                err = "non-finite primitive parameter";
+                return false;
+            }
+        RmPrim &q = s.prims[i];
+        std::memcpy(q.m, d.m, sizeof q.m);
+        q.type = d.type;
+        q.half[0] = q.half[1] = q.half[2] = 0.0f;
+        q.a = q.b = 0.0;
+        double local_radius;
+        if (d.type == 1) {  // box.ts:8-11,32-34
+            for (int k = 0; k < 3; ++k) q.half[k] = to_f32(d.params[k]);
+            local_radius = js_hypot3(q.half[0], q.half[1], q.half[2]);
+        } else if (d.type == 2) {  // torus.ts:27-29
+            q.a = d.params[0];
+            q.b = d.params[1];
+            local_radius = q.a + q.b;
+        } else {
+            q.a = d.params[0];
+            local_radius = q.a;
+        }
+        // Primitive.getWorldPosition (primitive.ts:20-30) and BoundingBox.fromPrimitive
+        // (boundingBox.ts:133-154): both invert the world->local matrix
+        Mat4 l2w = Mat4::identity();
+        const bool ok = invert4(q.m, l2w.m);
+        const float *m = ok ? l2w.m : q.m;
+        const double scale = js_max2(js_max2(js_hypot3(m[0], m[1], m[2]), js_hypot3(m[4], m[5], m[6])),
+                                     js_hypot3(m[8], m[9], m[10]));
+        const double pad = local_radius * scale * 1.5;
+        for (int k = 0; k < 3; ++k) {
+            s.world_pos[3 * i + k] = l2w.m[12 + k];
+            s.prim_lo[3 * i + k] = to_f32(double(l2w.m[12 + k]) - pad);
+            s.prim_hi[3 * i + k] = to_f32(double(l2w.m[12 + k]) + pad);
+        }
+    }
+    return build_accel(s, n, err);
 }
 
 void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]) {

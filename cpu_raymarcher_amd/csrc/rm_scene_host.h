@@ -12,9 +12,19 @@ namespace rmh {
 
 constexpr int kPresetCount = 19;  // sceneManager.ts:102-357
 
+// one primitive as the ABI hands it over (include/rm_raymarch.h: rm_prim)
+struct PrimDesc {
+    int type = 0;        // 0 sphere, 1 box, 2 torus
+    float m[16];         // world -> local, gl-matrix layout
+    double params[3];    // sphere: r; box: halfSize; torus: major, minor
+};
+
 struct HostScene {
     int accel = 0;
     int preset = 0;
+    bool general = false;         // RmPrim records instead of RmSphere
+    std::vector<RmPrim> prims;
+    std::vector<float> world_pos; // Primitive.getWorldPosition() per primitive (BVH sort key)
     std::vector<RmSphere> spheres;
     std::vector<double> radii;
     std::vector<float> prim_lo, prim_hi;  // padded AABBs, 3 floats per primitive
@@ -47,6 +57,17 @@ bool preset_spheres(int index, std::vector<float> &centers, std::vector<double> 
 // Builds spheres + acceleration structure.  Returns false and sets err on bad input.
 bool build_scene(HostScene &s, const float *centers, const double *radii, int n, int accel,
                  std::string &err);
+
+// SceneManager.getTransform (sceneManager.ts:21-37): world->local matrix of a primitive placed
+// at (x, y, z); rot == nullptr is the branch without a rotation argument
+void make_transform(double x, double y, double z, const float *rot, float out16[16]);
+
+// presets 0-4 (spheres) and 5, 7, 8, 9 (torus / boxes) as primitive descriptions; false for
+// presets that need SDF operators or the Mandelbulb
+bool preset_prims(int index, std::vector<PrimDesc> &out);
+
+// general scenes (any mix of spheres, boxes, tori, rotated or not)
+bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, std::string &err);
 
 // camera.ts:58-69,81-88 + raymarcher.ts:62-67
 void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]);

@@ -45,6 +45,16 @@ struct RmSphere {
     float rf;  // (float)radius, used only by the conservative candidate filter
 };
 
+// General primitive: world->local matrix as gl-matrix stores it (column-major
+// Float32Array) + the local SDF's parameters.  Scenes that contain anything but unrotated
+// spheres use these records (v1 kernel); pure sphere scenes keep the compact RmSphere path.
+struct RmPrim {
+    float m[16];
+    int32_t type;   // 0 sphere, 1 box, 2 torus
+    float half[3];  // box: halfSize (Float32Array, box.ts:8-11)
+    double a, b;    // sphere: radius, -; torus: majorRadius, minorRadius
+};
+
 #define RM_BVH_LEAF_MAX 255
 #define RM_MAX_STEPS 100
 #define RM_MAX_DIST 10.0
@@ -93,6 +103,9 @@ struct RmRenderParams {
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;
     int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)
+    int32_t general;     // 1: primitives are RmPrim records (`prims`), not RmSphere
+    int32_t reserved3;
+    const RmPrim *prims;
     double overshoot;    // AdaptiveStepV2/V3 overshootFactor (default 1.2)
     double step_size;    // FixedStep stepSize (default 0.1)
     const RmSphere *spheres;

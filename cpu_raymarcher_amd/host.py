@@ -74,6 +74,11 @@ class Scene:
         self.ctx.scene_from_spheres(centers, radii, self.accel_enum)
         self._uploaded = True
 
+    def loadPrims(self, prims):
+        """Build-defined: spheres / boxes / tori as (type, world_to_local[16], params)."""
+        self.ctx.scene_from_prims(prims, self.accel_enum)
+        self._uploaded = True
+
     @property
     def preset_for_job(self):
         return N.RM_SCENE_UPLOADED if self._uploaded else self.currentPresetIndex

@@ -132,8 +132,9 @@ RM_API int rm_preset_count(void);                   /* sceneManager.ts:363-365 *
 
 /* Replaces `new Scene(accel); scene.loadPreset(index)` (scene.ts:24-59,
  * raymarchWorker.ts:37-38): builds the primitive list, the BVH (bvh.ts:29-92) or Octree
- * (octree.ts:36-191), flattens it and uploads it.  Sphere-only presets 0..4 are native;
- * the others return RM_E_UNSUPPORTED. */
+ * (octree.ts:36-191), flattens it and uploads it.  Presets 0..4 (spheres) and 5, 7, 8, 9
+ * (torus, boxes) are native; presets with SDF operators or the Mandelbulb return
+ * RM_E_UNSUPPORTED. */
 RM_API int rm_scene_from_preset(rm_ctx *ctx, int32_t preset_index, int32_t accel);
 
 /* Build-defined scene entry: n spheres as SceneManager.createSphere(x, y, z, r) without
@@ -141,6 +142,26 @@ RM_API int rm_scene_from_preset(rm_ctx *ctx, int32_t preset_index, int32_t accel
  * (sphere.ts:5-9).  Selected in jobs by scene_preset_index = RM_SCENE_UPLOADED. */
 RM_API int rm_scene_from_spheres(rm_ctx *ctx, const float *centers_xyz, const double *radii,
                                  int32_t n, int32_t accel);
+
+/* General primitives: Sphere / Box / Torus with any world->local matrix
+ * (primitives/sphere.ts, box.ts, torus.ts; Primitive.sdf primitive.ts:33-39). */
+typedef enum rm_prim_type { RM_PRIM_SPHERE = 0, RM_PRIM_BOX = 1, RM_PRIM_TORUS = 2 } rm_prim_type;
+typedef struct rm_prim {
+    int32_t type;               /* rm_prim_type */
+    int32_t reserved;
+    float   world_to_local[16]; /* Primitive.transform, gl-matrix layout (column-major) */
+    double  params[3];          /* sphere: radius; box: halfSize x,y,z (stored f32, box.ts:10); */
+                                /* torus: majorRadius, minorRadius                               */
+    double  reserved2;
+} rm_prim;
+
+/* n primitives of any of the three kinds, selected in jobs by RM_SCENE_UPLOADED. */
+RM_API int rm_scene_from_prims(rm_ctx *ctx, const rm_prim *prims, int32_t n, int32_t accel);
+
+/* SceneManager.getTransform(x, y, z, rotation?) (sceneManager.ts:21-37): the world->local
+ * matrix of a primitive; rotation_xyz may be NULL (no rotation argument) or three Euler
+ * angles stored as binary32 like a gl-matrix vec3. */
+RM_API int rm_make_transform(double x, double y, double z, const float *rotation_xyz, float *world_to_local16);
 
 RM_API int rm_scene_get_info(const rm_ctx *ctx, rm_scene_info *out);
 

@@ -38,6 +38,9 @@ def lib():
         L.ro_scene_from_preset.argtypes = [C.c_int, C.c_char_p]
         L.ro_scene_from_spheres.restype = C.c_void_p
         L.ro_scene_from_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        L.ro_scene_from_prims.restype = C.c_void_p
+        L.ro_scene_from_prims.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.ro_scene_prims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ro_scene_free.argtypes = [C.c_void_p]
         L.ro_scene_set_angles.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ro_scene_distance.restype = C.c_double
@@ -67,10 +70,23 @@ class OracleScene:
     """Mirrors `new Scene(accel); scene.loadPreset(i); scene.camera.setAngles(p, y)`
     (reference src/workers/raymarchWorker.ts:37-39)."""
 
-    def __init__(self, preset=None, accel="None", spheres=None):
+    def __init__(self, preset=None, accel="None", spheres=None, prims=None):
+        """prims: list of dicts {type: 'sphere'|'box'|'torus', pos: (x,y,z), rot: (rx,ry,rz)|None,
+        r | half | radius} placed like SceneManager.createSphere/createBox/createTorus."""
         L = lib()
         self.accel = accel
-        if spheres is not None:
+        if prims is not None:
+            desc = np.zeros((len(prims), 11), np.float64)
+            for i, d in enumerate(prims):
+                desc[i, 0] = {"sphere": 0, "box": 1, "torus": 2}[d["type"]]
+                desc[i, 1:4] = d["pos"]
+                desc[i, 4:7] = d["rot"] if d.get("rot") is not None else (np.nan, 0, 0)
+                if d["type"] == "box":
+                    desc[i, 7:10] = d["half"]
+                else:
+                    desc[i, 7] = d["r"] if d["type"] == "sphere" else d["radius"]
+            self._h = L.ro_scene_from_prims(_p(desc), len(prims), accel.encode())
+        elif spheres is not None:
             s = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 4)
             xyz = np.ascontiguousarray(s[:, :3])
             rad = np.ascontiguousarray(s[:, 3])
@@ -119,6 +135,16 @@ class OracleScene:
         lib().ro_scene_spheres(self._h, _p(c), _p(r))
         return c, r
 
+    def prims(self):
+        """(type, world_to_local float32[16], params float64[3]) per primitive: what the product's
+        rm_scene_from_prims takes."""
+        n = self.stats()["n"]
+        t = np.zeros(n, np.int32)
+        m = np.zeros((n, 16), np.float32)
+        par = np.zeros((n, 3), np.float64)
+        lib().ro_scene_prims(self._h, _p(t), _p(m), _p(par))
+        return [(int(t[i]), m[i].copy(), par[i].copy()) for i in range(n)]
+
     def distance(self, p):
         pos = np.asarray(p, np.float32)
         cnt = C.c_uint32(0)
@@ -158,6 +184,24 @@ def diagnostics(sdf, iters):
     lib().ro_diagnostics(_p(sdf), _p(iters), sdf.size, _p(out))
     return {"total_sdf": int(out[0]), "max_sdf": int(out[1]), "min_sdf": int(out[2]),
             "total_iters": int(out[3])}
+
+
+def synthetic_mixed_prims(n=40, seed=7):
+    """Deterministic mix of spheres, boxes and tori, half of them with a rotation argument."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        kind = ("sphere", "box", "torus")[i % 3]
+        d = {"type": kind, "pos": [float(np.float32(v)) for v in rng.uniform(-1.3, 1.3, 3)],
+             "rot": [float(np.float32(v)) for v in rng.uniform(-3.2, 3.2, 3)] if i % 2 else None}
+        if kind == "sphere":
+            d["r"] = float(rng.uniform(0.08, 0.3))
+        elif kind == "box":
+            d["half"] = [float(np.float32(v)) for v in rng.uniform(0.05, 0.3, 3)]
+        else:
+            d["radius"] = float(rng.uniform(0.1, 0.3))
+        out.append(d)
+    return out
 
 
 def synthetic_spheres(n=10000, seed=0x5EED5EED):

@@ -57,6 +57,16 @@ CASES = {
                             js="full"),
     "M5_v3_270p_octree10k": dict(synthetic=10000, accel="Octree", width=480, height=270, shader="iteration-heatmap",
                                  algorithm="adaptive-step-v3", overshootFactor=1.35, js="full"),
+    # boxes, tori, rotated transforms
+    "N3_torus_360p_bvh": dict(preset=5, accel="BVH", width=640, height=360, shader="phong", pitch=0.4, yaw=0.9, js="full"),
+    "N3_cube_360p_none_v2march": dict(preset=7, accel="None", width=640, height=360, shader="normal",
+                                      algorithm="adaptive-step-v2", pitch=-0.3, yaw=0.5, js="full"),
+    "N3_sphere_and_cube_360p_octree": dict(preset=8, accel="Octree", width=640, height=360, shader="sdf-heatmap", js="full"),
+    "N3_pyramid_360p_bvh": dict(preset=9, accel="BVH", width=640, height=360, shader="iteration-heatmap", pitch=0.5,
+                                yaw=-1.0, js="full"),
+    "N3_mixed40_360p_bvh": dict(mixed=40, accel="BVH", width=640, height=360, shader="phong", pitch=0.2, yaw=0.3, js="full"),
+    "N3_mixed40_360p_octree": dict(mixed=40, accel="Octree", width=640, height=360, shader="normal", pitch=-0.6,
+                                   yaw=2.0, js="full"),
     "M6_fixed_default_270p_none": dict(preset=2, accel="None", width=480, height=270, shader="sdf-heatmap",
                                        algorithm="fixed-step", js="full"),
 }
@@ -73,7 +83,8 @@ def c_render(cfg, y0=None, y1=None, width=None, height=None):
     y0 = 0 if y0 is None else y0
     y1 = H if y1 is None else y1
     spheres = O.synthetic_spheres(cfg["synthetic"]) if "synthetic" in cfg else None
-    sc = O.OracleScene(preset=cfg.get("preset"), accel=cfg["accel"], spheres=spheres)
+    prims = O.synthetic_mixed_prims(cfg["mixed"]) if "mixed" in cfg else None
+    sc = O.OracleScene(preset=cfg.get("preset"), accel=cfg["accel"], spheres=spheres, prims=prims)
     sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0))
     bands = []
     step = max(1, (y1 - y0 + 4 * THREADS - 1) // (4 * THREADS))
@@ -100,6 +111,8 @@ def js_render(cfg, y0=None, y1=None, width=None, height=None):
             sp = O.synthetic_spheres(cfg["synthetic"])
             sp.astype(np.float64).tofile(os.path.join(td, "spheres.f64"))
             j["spheres_file"] = os.path.join(td, "spheres.f64")
+        elif "mixed" in cfg:
+            j["prims"] = O.synthetic_mixed_prims(cfg["mixed"])
         else:
             j["preset"] = cfg["preset"]
         for k in ("algorithm", "overshootFactor", "stepSize"):

@@ -15,9 +15,11 @@ NAMES = ("depth", "normal", "sdf", "iters")
 
 
 def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
-               overshoot=None, step=None):
+               overshoot=None, step=None, prims=None):
     sc = rm.Scene(accel, ctx=ctx)
-    if spheres is not None:
+    if prims is not None:  # (type, world_to_local, params) triples, e.g. OracleScene.prims()
+        sc.loadPrims(prims)
+    elif spheres is not None:
         sc.loadSpheres(spheres[:, :3], spheres[:, 3])
     else:
         sc.loadPreset(preset)
@@ -30,8 +32,8 @@ def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=
 
 
 def cpu_render(oracle, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
-               overshoot=None, step=None):
-    sc = oracle.OracleScene(preset=preset, accel=accel, spheres=spheres)
+               overshoot=None, step=None, prims=None):
+    sc = oracle.OracleScene(preset=preset, accel=accel, spheres=spheres, prims=prims)
     sc.set_angles(*ang)
     y0, y1 = rows if rows else (0, H)
     return sc.render(W, H, y0, y1, algorithm=algorithm, overshoot_factor=overshoot, step_size=step)
@@ -176,7 +178,7 @@ def test_empty_scene_and_bad_inputs(rm, gpu_ctx, oracle):
     sc = rm.Scene("BVH", ctx=gpu_ctx)
     bufs = (np.zeros(16, np.uint8), np.zeros(48, np.uint8), np.zeros(16, np.uint16), np.zeros(16, np.uint16))
     with pytest.raises(rm.RmUnsupported):
-        sc.loadPreset(9)
+        sc.loadPreset(10)  # "Smooth Union": SDF operator, not native
     sc.camera.pitch = float("nan")
     with pytest.raises(rm.RmError):
         rm.SphereTracer().runRaymarcher(sc, *bufs, 4, 4)
@@ -308,9 +310,12 @@ def test_golden_fixtures_at_baseline_sizes(rm, gpu_ctx, oracle, golden, golden_c
         cfg = g["config"]
         W, H = cfg["width"], cfg["height"]
         spheres = oracle.synthetic_spheres(cfg["synthetic"]) if "synthetic" in cfg else None
+        prims = None
+        if "mixed" in cfg:  # the product receives the matrices the oracle's SceneManager restatement made
+            prims = oracle.OracleScene(accel="None", prims=oracle.synthetic_mixed_prims(cfg["mixed"])).prims()
         got = gpu_render(rm, gpu_ctx, cfg.get("preset"), cfg["accel"], W, H, (cfg.get("pitch", 0.0), cfg.get("yaw", 0.0)),
                          spheres=spheres, algorithm=cfg.get("algorithm", "sphere-tracer"),
-                         overshoot=cfg.get("overshootFactor"), step=cfg.get("stepSize"))
+                         overshoot=cfg.get("overshootFactor"), step=cfg.get("stepSize"), prims=prims)
         rgba = np.zeros(4 * W * H, np.uint8)
         rm.createShadingModelFromValue(cfg["shader"], gpu_ctx).shade(rgba, *got, W, H)
         c = g["crop"]
@@ -364,3 +369,33 @@ def test_analytics_sweep_frames(rm, gpu_ctx, oracle):
         osc.set_angles(0.0, yaw)
         assert sc.camera.yaw == yaw
         assert_same(bufs, osc.render(W, H), "sweep frame %d" % frame)
+
+
+@pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
+@pytest.mark.parametrize("preset", [5, 7, 8, 9])
+def test_box_and_torus_presets(rm, gpu_ctx, oracle, preset, accel):
+    """Torus (rotated), Cube, Sphere and Cube, Pyramid of Boxes -- general
+    transformMat4, Box / Torus localSdf, bounds from the inverted matrix."""
+    for alg, ang in (("sphere-tracer", (0.3, -0.8)), ("adaptive-step-v3", (-0.5, 2.4))):
+        got = gpu_render(rm, gpu_ctx, preset, accel, 220, 140, ang, algorithm=alg)
+        assert_same(got, cpu_render(oracle, preset, accel, 220, 140, ang, algorithm=alg), "preset %d %s %s" % (preset, accel, alg))
+
+
+def test_mixed_rotated_primitives_and_make_transform(rm, gpu_ctx, oracle):
+    desc = oracle.synthetic_mixed_prims(60, seed=11)
+    osc = oracle.OracleScene(accel="None", prims=desc)
+    triples = osc.prims()
+    # rm_make_transform == SceneManager.getTransform as the oracle restates it
+    for d, (t, m, par) in zip(desc, triples):
+        mine = rm.make_transform(*d["pos"], rotation=d["rot"])
+        assert np.array_equal(mine, m), d
+    for accel in ("None", "BVH", "Octree"):
+        got = gpu_render(rm, gpu_ctx, None, accel, 260, 150, (0.1, 0.9), prims=triples)
+        assert_same(got, cpu_render(oracle, None, accel, 260, 150, (0.1, 0.9), prims=desc), "mixed60 " + accel)
+    sc = rm.Scene("BVH", ctx=gpu_ctx)
+    sc.loadPrims(triples)
+    pts = np.random.default_rng(3).uniform(-2, 2, (500, 3)).astype(np.float32)
+    d, c = sc.getDistances(pts)
+    ob = oracle.OracleScene(accel="BVH", prims=desc)
+    for k in range(0, 500, 5):
+        assert (d[k], c[k]) == ob.distance(pts[k])

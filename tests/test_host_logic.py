@@ -58,7 +58,7 @@ def test_partition_rows_matches_main_ts(rm):
 
 def test_host_only_context_builds_scenes_like_the_oracle(rm, oracle):
     ctx = rm.Context(None)
-    for preset in range(5):
+    for preset in (0, 1, 2, 3, 4, 5, 7, 8, 9):
         for accel, name in ((0, "None"), (1, "Octree"), (2, "BVH")):
             ctx.scene_from_preset(preset, accel)
             info = ctx.scene_info()
@@ -97,7 +97,9 @@ def test_error_codes_without_a_device(rm):
     from cpu_raymarcher_amd import _native as N
     ctx = rm.Context(None)
     with pytest.raises(rm.RmUnsupported):
-        ctx.scene_from_preset(99, 2)  # scene.ts:39 clamps to preset 18 ("67"), which is not sphere-only
+        ctx.scene_from_preset(99, 2)  # scene.ts:39 clamps to preset 18 ("67"): SDF operators, not native
+    with pytest.raises(rm.RmUnsupported):
+        ctx.scene_from_preset(6, 0)  # "Rounded Box": Round operator
     ctx.scene_from_preset(-5, 2)  # clamps to preset 0
     assert ctx.scene_info()["n_prims"] == 1
     scene = rm.Scene("BVH", ctx=ctx)

@@ -45,6 +45,7 @@ def test_host_only_context_refuses_to_render(addon):
     dict(preset=2, accel="BVH", width=160, height=90, shader="sdf-heatmap", algorithm="no-such-marcher"),
     dict(preset=3, accel="BVH", width=160, height=90, shader="sdf-heatmap", algorithm="adaptive-step-v3", overshootFactor=1.4),
     dict(preset=3, accel="Octree", width=160, height=90, shader="normal", algorithm="fixed-step"),
+    dict(preset=5, accel="BVH", width=160, height=90, shader="phong", pitch=0.4, yaw=0.9),  # rotated torus
 ])
 def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
@@ -71,7 +72,7 @@ def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
 
 @pytest.mark.gpu
 def test_node_worker_reports_unsupported(addon, tmp_path):
-    cfg = dict(preset=7, accel="BVH", width=16, height=16, shader="normal")  # "Cube": a Box primitive
+    cfg = dict(preset=6, accel="BVH", width=16, height=16, shader="normal")  # "Rounded Box": Round operator
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
     p = subprocess.run([NODE, os.path.join(ROOT, "native", "render_cli.js"), str(tmp_path / "cfg.json"),
                         str(tmp_path / "out")], stdout=subprocess.PIPE)

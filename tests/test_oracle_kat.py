@@ -111,7 +111,7 @@ def test_empty_and_degenerate_inputs(oracle):
     d, n, s, i = sc.render(8, 8, 5, 5)  # empty tile
     assert d.size == 0
     with pytest.raises(ValueError):
-        oracle.OracleScene(preset=7, accel="None")  # box preset: out of scope
+        oracle.OracleScene(preset=6, accel="None")  # Round operator: out of scope (N4)
     assert np.array_equal(sc.render(8, 8, algorithm="no-such-marcher")[2], sc.render(8, 8)[2])  # default branch
 
 
@@ -122,7 +122,8 @@ def test_golden_small_cases(oracle, golden):
         if cfg["width"] * cfg["height"] > 700 * 400:
             continue  # full-size cases are checked on the GPU box against the HIP path
         spheres = oracle.synthetic_spheres(cfg["synthetic"]) if "synthetic" in cfg else None
-        sc = oracle.OracleScene(preset=cfg.get("preset"), accel=cfg["accel"], spheres=spheres)
+        prims = oracle.synthetic_mixed_prims(cfg["mixed"]) if "mixed" in cfg else None
+        sc = oracle.OracleScene(preset=cfg.get("preset"), accel=cfg["accel"], spheres=spheres, prims=prims)
         sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0))
         d, n, s, i = sc.render(cfg["width"], cfg["height"], algorithm=cfg.get("algorithm", "sphere-tracer"),
                                overshoot_factor=cfg.get("overshootFactor"), step_size=cfg.get("stepSize"))

@@ -36,6 +36,12 @@ WORKLOADS = {
     "C5": dict(name="C5: synthetic 10000 random spheres (splitmix64 0x5EED5EED), 3840x2160, sphere-tracing + Octree, "
                     "iteration-heatmap shader",
                synthetic=10000, accel="Octree", width=3840, height=2160, shader="iteration-heatmap"),
+    # boxes / tori / rotated transforms (not BASELINE configs; same frame size as C3)
+    "N3": dict(name="N3: Pyramid of Boxes (preset 9), 3840x2160, sphere-tracing + BVH, Phong shader",
+               preset=9, accel="BVH", width=3840, height=2160, shader="phong"),
+    "N3mixed": dict(name="N3: 40 synthetic mixed primitives (spheres, boxes, tori, rotated), 3840x2160, "
+                         "sphere-tracing + BVH, Phong shader",
+                    mixed=40, accel="BVH", width=3840, height=2160, shader="phong"),
 }
 
 
@@ -48,7 +54,8 @@ def cpu_baseline(wl, budget_s=20.0):
     from oracle import oracle as O
     W, H = wl["width"], wl["height"]
     spheres = O.synthetic_spheres(wl["synthetic"]) if "synthetic" in wl else None
-    sc = O.OracleScene(preset=wl.get("preset"), accel=wl["accel"], spheres=spheres)
+    prims = O.synthetic_mixed_prims(wl["mixed"]) if "mixed" in wl else None
+    sc = O.OracleScene(preset=wl.get("preset"), accel=wl["accel"], spheres=spheres, prims=prims)
     # 16 = the CPU share of a one-GPU box (the host itself reports every core of the node)
     cores = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16))
     t0 = time.time()
@@ -146,6 +153,18 @@ def main():
         from oracle.oracle import synthetic_spheres  # scene generator only (SURVEY 8d C5 definition)
         sp = synthetic_spheres(wl["synthetic"])
         scene.loadSpheres(sp[:, :3], sp[:, 3])
+    elif "mixed" in wl:
+        from oracle.oracle import synthetic_mixed_prims  # scene generator only
+        triples = []
+        for d in synthetic_mixed_prims(wl["mixed"]):
+            m = R.make_transform(*d["pos"], rotation=d["rot"])  # SceneManager.getTransform
+            if d["type"] == "sphere":
+                triples.append((0, m, [d["r"]]))
+            elif d["type"] == "box":
+                triples.append((1, m, d["half"]))
+            else:
+                triples.append((2, m, [d["radius"], d["radius"] / 4]))  # createTorus: minor = radius / 4
+        scene.loadPrims(triples)
     else:
         scene.loadPreset(wl["preset"])
     tracer = R.SphereTracer()

@@ -16,9 +16,9 @@ _lib = None
 
 def build(force=False):
     """Compile rm_oracle.c with gcc (Makefile in this directory)."""
-    src = os.path.join(_HERE, "rm_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("rm_oracle.c", "ro_jsmath.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "librm_oracle.so"])
     return _LIB_PATH
@@ -41,6 +41,11 @@ def lib():
         L.ro_scene_from_prims.restype = C.c_void_p
         L.ro_scene_from_prims.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.ro_scene_prims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_scene_from_nodes.restype = C.c_void_p
+        L.ro_scene_from_nodes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p]
+        L.ro_scene_nodes.restype = C.c_int
+        L.ro_scene_nodes.argtypes = [C.c_void_p] * 6
+        L.ro_set_time.argtypes = [C.c_double]
         L.ro_scene_free.argtypes = [C.c_void_p]
         L.ro_scene_set_angles.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ro_scene_distance.restype = C.c_double
@@ -66,6 +71,55 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+NODE_TYPES = {"sphere": 0, "box": 1, "torus": 2, "mandelbulb": 3, "round": 10, "smoothUnion": 11, "smoothSub": 12,
+              "twist": 13, "repetition": 14, "anim": 15}
+
+
+def _flatten_nodes(prims):
+    """Expression forest (nested dicts, the format rm_oracle.js takes as cfg.prims) -> the 16-double
+    records of ro_scene_from_nodes + root indices."""
+    rows, roots = [], []
+
+    def add(d):
+        t = d["type"]
+        r = [0.0] * 16
+        r[0] = NODE_TYPES[t]
+        r[4] = float("nan")
+        r[13] = r[14] = -1
+        if t in ("sphere", "box", "torus", "mandelbulb"):
+            r[1:4] = [float(v) for v in d["pos"]]
+            if d.get("rot") is not None:
+                r[4:7] = [float(v) for v in d["rot"]]
+            if t == "sphere":
+                r[7] = d["r"]
+            elif t == "box":
+                r[7:10] = [float(v) for v in d["half"]]
+            elif t == "torus":
+                r[7] = d["radius"]
+            else:
+                r[7:11] = [d["power"], d["iterations"], 1.0 if d["animate"] else 0.0, d["speed"]]
+        else:
+            r[13] = add(d["a"])
+            if t in ("smoothUnion", "smoothSub"):
+                r[14] = add(d["b"])
+                r[7] = d["k"]
+            elif t == "round":
+                r[7] = d["radius"]
+            elif t == "twist":
+                r[7] = d["amount"]
+            elif t == "repetition":
+                r[7:10] = [float(v) for v in d["spacing"]]
+            else:
+                r[7:10] = [float(v) for v in d["direction"]]
+                r[10], r[11] = d["amplitude"], d["speed"]
+        rows.append(r)
+        return len(rows) - 1
+
+    for d in prims:
+        roots.append(add(d))
+    return np.array(rows, np.float64).reshape(-1, 16), np.array(roots, np.int32)
+
+
 class OracleScene:
     """Mirrors `new Scene(accel); scene.loadPreset(i); scene.camera.setAngles(p, y)`
     (reference src/workers/raymarchWorker.ts:37-39)."""
@@ -75,7 +129,10 @@ class OracleScene:
         r | half | radius} placed like SceneManager.createSphere/createBox/createTorus."""
         L = lib()
         self.accel = accel
-        if prims is not None:
+        if prims is not None and any(d["type"] not in ("sphere", "box", "torus") for d in prims):
+            desc, roots = _flatten_nodes(prims)
+            self._h = L.ro_scene_from_nodes(_p(desc), len(desc), _p(roots), len(roots), accel.encode())
+        elif prims is not None:
             desc = np.zeros((len(prims), 11), np.float64)
             for i, d in enumerate(prims):
                 desc[i, 0] = {"sphere": 0, "box": 1, "torus": 2}[d["type"]]
@@ -145,7 +202,20 @@ class OracleScene:
         lib().ro_scene_prims(self._h, _p(t), _p(m), _p(par))
         return [(int(t[i]), m[i].copy(), par[i].copy()) for i in range(n)]
 
-    def distance(self, p):
+    def nodes(self):
+        """Flattened expression forest as the product's rm_scene_from_nodes takes it:
+        (list of (type, child_a, child_b, world_to_local float32[16], params float64[6]), roots)."""
+        n = lib().ro_scene_nodes(self._h, None, None, None, None, None)
+        t = np.zeros(n, np.int32)
+        kids = np.zeros((n, 2), np.int32)
+        m = np.zeros((n, 16), np.float32)
+        par = np.zeros((n, 6), np.float64)
+        roots = np.zeros(self.stats()["n"], np.int32)
+        lib().ro_scene_nodes(self._h, _p(t), _p(kids), _p(m), _p(par), _p(roots))
+        return [(int(t[i]), int(kids[i, 0]), int(kids[i, 1]), m[i].copy(), par[i].copy()) for i in range(n)], roots.tolist()
+
+    def distance(self, p, time=0.0):
+        lib().ro_set_time(float(time))
         pos = np.asarray(p, np.float32)
         cnt = C.c_uint32(0)
         d = lib().ro_scene_distance(self._h, _p(pos), C.byref(cnt))

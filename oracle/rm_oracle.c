@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "ro_jsmath.h" /* Math.sin/cos/atan2/asin/pow/log/round as V8 computes them (fdlibm ports) */
+
 #if defined(__FP_FAST_FMA) && defined(__FMA__)
 /* fine: we still rely on -ffp-contract=off so a*b+c is never fused */
 #endif
@@ -263,15 +265,28 @@ static inline double vec3_dot(const float *a, const float *b) {
 
 typedef struct { float min[3], max[3]; } BBox; /* boundingBox.ts:5-12 (vec3.clone -> f32) */
 
-/* primitives/primitive.ts:3-44 + primitives/sphere.ts:4-18 (Sphere only) */
-enum { PRIM_SPHERE = 0, PRIM_BOX = 1, PRIM_TORUS = 2 };
-typedef struct {
-    float transform[16]; /* world -> local */
+/* primitives/primitive.ts:3-44, primitives/{sphere,box,torus,mandelbulb}.ts and the operator
+ * classes of primitive_operations/ (each "extends Primitive" and wraps one or two operands) */
+enum { PRIM_SPHERE = 0, PRIM_BOX = 1, PRIM_TORUS = 2, PRIM_MANDELBULB = 3,
+       OP_ROUND = 10, OP_SMOOTH_UNION = 11, OP_SMOOTH_SUB = 12, OP_TWIST = 13, OP_REPETITION = 14, OP_ANIM = 15 };
+typedef struct Prim {
+    float transform[16]; /* world -> local; wrappers share their operand's (round.ts:9 ...), unions use identity */
     int type;
     double radius;       /* Sphere: stays a JS double (sphere.ts:5-9) */
     float halfSize[3];   /* Box: vec3.clone(halfSize) -> Float32Array (box.ts:8-11) */
     double majorRadius, minorRadius; /* Torus (torus.ts:8-12) */
+    struct Prim *a, *b;  /* operands (owned) */
+    double k;            /* Round.radius | smoothness | twistAmount | AnimatedTranslate.amplitude */
+    double speed;        /* AnimatedTranslate.speed | Mandelbulb.animationSpeed */
+    float vec[3];        /* Repetition.spacing | AnimatedTranslate.direction (normalised, f32) */
+    double power;        /* Mandelbulb */
+    int iterations, enableAnimation;
 } Prim;
+
+/* Scene.updateTime (scene.ts:135-140) hands `time` to every animated primitive before a render
+ * (raymarcher.ts:58-59); renders run in parallel threads over one const scene, so the value
+ * lives in thread-local storage for the duration of a call. */
+static __thread double g_time = 0.0;
 
 typedef struct BVHNode {
     BBox bounds;
@@ -303,18 +318,111 @@ typedef struct ro_scene {
     float cameraTransform[16];
 } ro_scene;
 
-/* primitive.ts:20-30 getWorldPosition */
+static inline double len3d(double x, double y, double z) {
+    if (g_length_uses_sqrt) return sqrt(x * x + y * y + z * z);
+    return ro_hypot3(x, y, z);
+}
+
+/* primitive.ts:20-30 getWorldPosition and its overrides (round.ts:30-33, twist.ts:42-45,
+ * repetition.ts:35-38, animatedTranslate.ts:55-57: the operand's; smoothUnion.ts:52-60: the
+ * midpoint; smoothSubstraction.ts:41-44: the first operand's) */
 static void prim_world_position(const Prim *p, float *out) {
+    if (p->type == OP_SMOOTH_UNION) {
+        float p1[3], p2[3];
+        prim_world_position(p->a, p1);
+        prim_world_position(p->b, p2);
+        for (int i = 0; i < 3; i++) out[i] = f32(((double)p1[i] + (double)p2[i]) / 2);
+        return;
+    }
+    if (p->type >= OP_ROUND) { prim_world_position(p->a, out); return; }
     float l2w[16];
     mat4_identity(l2w);
     mat4_invert(l2w, p->transform);
     out[0] = l2w[12]; out[1] = l2w[13]; out[2] = l2w[14];
 }
 
-/* primitive.ts:33-39 sdf + sphere.ts:12-14 localSdf */
-static inline double prim_sdf(const Prim *p, const float *pos) {
+/* mandelbulb.ts:37-78 localSdf.  z is a vec3 (Float32Array): every z[i] store rounds to binary32 */
+static double mandelbulb_local_sdf(const Prim *m, const float *local) {
+    const float p[3] = {local[0], local[2], local[1]};
+    float z[3] = {p[0], p[1], p[2]};
+    double dr = 1.0, r = 0.0;
+    for (int i = 0; i < m->iterations; i++) {
+        r = vec3_length(z);
+        if (r > 2.0) break;
+        double theta = js_atan2(z[1], z[0]);
+        double phi = js_asin((double)z[2] / r);
+        if (m->enableAnimation) phi += g_time * m->speed;
+        dr = js_pow(r, m->power - 1.0) * dr * m->power + 1.0;
+        r = js_pow(r, m->power);
+        theta = theta * m->power;
+        phi = phi * m->power;
+        z[0] = f32(r * js_cos(theta) * js_cos(phi) + (double)p[0]);
+        z[1] = f32(r * js_sin(theta) * js_cos(phi) + (double)p[1]);
+        z[2] = f32(r * js_sin(phi) + (double)p[2]);
+    }
+    return 0.5 * js_log(r) * r / dr;
+}
+
+static double prim_sdf(const Prim *p, const float *pos);
+
+/* the "convert local position back to world space" prologue the operators share
+ * (round.ts:17-21, twist.ts:16-19, repetition.ts:14-18, smoothUnion.ts:20-23) */
+static void op_world_pos(const Prim *p, const float *local, float *world) {
+    float l2w[16];
+    mat4_identity(l2w);
+    mat4_invert(l2w, p->transform);
+    vec3_transformMat4(world, local, l2w);
+}
+
+/* primitive.ts:33-39 sdf + the localSdf of each class */
+static double prim_sdf(const Prim *p, const float *pos) {
     float local[3];
     vec3_transformMat4(local, pos, p->transform);
+    if (p->type >= OP_ROUND) {
+        float w[3];
+        switch (p->type) {
+        case OP_ROUND: /* round.ts:16-25 */
+            op_world_pos(p, local, w);
+            return prim_sdf(p->a, w) - p->k;
+        case OP_TWIST: { /* twist.ts:14-36 */
+            op_world_pos(p, local, w);
+            double c = js_cos(p->k * (double)w[1]), sn = js_sin(p->k * (double)w[1]);
+            float t[3] = {f32(c * (double)w[0] - sn * (double)w[2]), w[1], f32(sn * (double)w[0] + c * (double)w[2])};
+            return prim_sdf(p->a, t);
+        }
+        case OP_REPETITION: { /* repetition.ts:13-29 */
+            op_world_pos(p, local, w);
+            float q[3];
+            for (int i = 0; i < 3; i++)
+                q[i] = f32((double)w[i] - (double)p->vec[i] * js_round((double)w[i] / (double)p->vec[i]));
+            return prim_sdf(p->a, q);
+        }
+        case OP_ANIM: { /* animatedTranslate.ts:34-49: the operand re-applies its own transform */
+            double offset = js_sin(g_time * p->speed) * p->k;
+            float adj[3];
+            for (int i = 0; i < 3; i++) {
+                float off = f32((double)p->vec[i] * offset);
+                adj[i] = f32((double)local[i] - (double)off);
+            }
+            return prim_sdf(p->a, adj);
+        }
+        case OP_SMOOTH_UNION: { /* smoothUnion.ts:18-35 */
+            op_world_pos(p, local, w);
+            double d1 = prim_sdf(p->a, w), d2 = prim_sdf(p->b, w);
+            double k = p->k * 4.0;
+            double h = js_max(k - fabs(d1 - d2), 0.0);
+            return js_min(d1, d2) - h * h * 0.25 / k;
+        }
+        default: { /* OP_SMOOTH_SUB, smoothSubstraction.ts:16-34 */
+            op_world_pos(p, local, w);
+            double d1 = prim_sdf(p->a, w), d2 = prim_sdf(p->b, w);
+            double k = p->k * 4.0;
+            double h = js_max(k - fabs(d1 + d2), 0.0);
+            return js_max(d1, -d2) + h * h * 0.25 / k;
+        }
+        }
+    }
+    if (p->type == PRIM_MANDELBULB) return mandelbulb_local_sdf(p, local);
     if (p->type == PRIM_BOX) { /* box.ts:13-30 */
         float q[3], outside[3];
         for (int i = 0; i < 3; i++) {
@@ -334,8 +442,27 @@ static inline double prim_sdf(const Prim *p, const float *pos) {
     return vec3_length(local) - p->radius;
 }
 
-/* getLocalBoundingRadius: sphere.ts:16-18, box.ts:32-34, torus.ts:27-29 */
+/* getLocalBoundingRadius: sphere.ts:16-18, box.ts:32-34, torus.ts:27-29, mandelbulb.ts:80-83,
+ * round.ts:27-30, twist.ts:38-41, repetition.ts:31-34, animatedTranslate.ts:51-54,
+ * smoothUnion.ts:37-49, smoothSubstraction.ts:36-39 */
 static double prim_local_radius(const Prim *p) {
+    switch (p->type) {
+    case PRIM_MANDELBULB: return 2.5;
+    case OP_ROUND: return prim_local_radius(p->a) + p->k;
+    case OP_TWIST: return prim_local_radius(p->a);
+    case OP_REPETITION: return INFINITY;
+    case OP_ANIM: return prim_local_radius(p->a) + p->k;
+    case OP_SMOOTH_SUB: return prim_local_radius(p->a);
+    case OP_SMOOTH_UNION: {
+        double r1 = prim_local_radius(p->a), r2 = prim_local_radius(p->b);
+        float p1[3], p2[3];
+        prim_world_position(p->a, p1);
+        prim_world_position(p->b, p2);
+        double centerDist = len3d((double)p2[0] - (double)p1[0], (double)p2[1] - (double)p1[1], (double)p2[2] - (double)p1[2]);
+        return js_max(r1, r2) + centerDist * 0.5;
+    }
+    default: break;
+    }
     if (p->type == PRIM_BOX) return vec3_length(p->halfSize);
     if (p->type == PRIM_TORUS) return p->majorRadius + p->minorRadius;
     return p->radius;
@@ -791,6 +918,77 @@ static void make_torus(Prim *p, double x, double y, double z, double radius, con
     p->minorRadius = radius / 4;
 }
 
+/* gl-matrix mat4.scale(out, a, v), in place */
+static void mat4_scale(float *m, double x, double y, double z) {
+    for (int i = 0; i < 4; i++) {
+        m[i] = f32((double)m[i] * x);
+        m[4 + i] = f32((double)m[4 + i] * y);
+        m[8 + i] = f32((double)m[8 + i] * z);
+    }
+}
+
+/* by-value constructors for expression trees (sceneManager.ts:39-100) */
+static Prim mk_sphere(double x, double y, double z, double radius, const float *rot) {
+    Prim p; memset(&p, 0, sizeof p);
+    get_transform(p.transform, x, y, z, rot);
+    p.type = PRIM_SPHERE; p.radius = radius;
+    return p;
+}
+static Prim mk_box(double x, double y, double z, double hx, double hy, double hz, const float *rot) {
+    Prim p; memset(&p, 0, sizeof p);
+    make_box(&p, x, y, z, hx, hy, hz, rot);
+    return p;
+}
+static Prim mk_torus(double x, double y, double z, double radius, const float *rot) {
+    Prim p; memset(&p, 0, sizeof p);
+    make_torus(&p, x, y, z, radius, rot);
+    return p;
+}
+/* sceneManager.ts:51-73 createMandelbulb: the world->local matrix is post-scaled by 0.5 */
+static Prim mk_mandelbulb(double x, double y, double z, double power, int iterations, int anim, double speed, const float *rot) {
+    Prim p; memset(&p, 0, sizeof p);
+    get_transform(p.transform, x, y, z, rot);
+    mat4_scale(p.transform, 0.5, 0.5, 0.5);
+    p.type = PRIM_MANDELBULB; p.power = power; p.iterations = iterations; p.enableAnimation = anim; p.speed = speed;
+    return p;
+}
+static Prim *heap_prim(Prim v) {
+    Prim *h = (Prim *)malloc(sizeof *h);
+    *h = v;
+    return h;
+}
+/* Round / Twist / Repetition / AnimatedTranslate: super(primitive.transform) */
+static Prim mk_wrap(int type, Prim operand, double k) {
+    Prim p; memset(&p, 0, sizeof p);
+    memcpy(p.transform, operand.transform, sizeof p.transform);
+    p.type = type; p.k = k; p.a = heap_prim(operand);
+    return p;
+}
+static Prim mk_repetition(Prim operand, double sx, double sy, double sz) {
+    Prim p = mk_wrap(OP_REPETITION, operand, 0);
+    p.vec[0] = f32(sx); p.vec[1] = f32(sy); p.vec[2] = f32(sz);
+    return p;
+}
+/* animatedTranslate.ts:14-27: direction is normalised into a fresh vec3 */
+static Prim mk_anim(Prim operand, double dx, double dy, double dz, double amplitude, double speed) {
+    Prim p = mk_wrap(OP_ANIM, operand, amplitude);
+    float d[3] = {f32(dx), f32(dy), f32(dz)};
+    vec3_normalize(p.vec, d);
+    p.speed = speed;
+    return p;
+}
+/* SmoothUnion / SmoothSubtraction: super(mat4.create()) */
+static Prim mk_smooth(int type, Prim a, Prim b, double k) {
+    Prim p; memset(&p, 0, sizeof p);
+    mat4_identity(p.transform);
+    p.type = type; p.k = k; p.a = heap_prim(a); p.b = heap_prim(b);
+    return p;
+}
+static void prim_free_children(Prim *p) {
+    if (p->a) { prim_free_children(p->a); free(p->a); }
+    if (p->b) { prim_free_children(p->b); free(p->b); }
+}
+
 static ro_scene *scene_alloc(int n, const char *accel) {
     ro_scene *s = (ro_scene *)calloc(1, sizeof *s);
     s->n = n;
@@ -803,8 +1001,7 @@ static ro_scene *scene_alloc(int n, const char *accel) {
 
 #define RO_PRESET_COUNT 19 /* sceneManager.ts:102-357 */
 
-/* sceneManager.ts:102-170 -- the sphere-only presets 0..4.  Returns NULL for the
- * presets that need non-sphere primitives (out of scope). */
+/* sceneManager.ts:102-357 -- all 19 presets */
 ro_scene *ro_scene_from_preset(int index, const char *accel) {
     /* scene.ts:39 / sceneManager.ts:359-361 clamp */
     if (index < 0) index = 0;
@@ -873,8 +1070,70 @@ ro_scene *ro_scene_from_preset(int index, const char *accel) {
         make_box(&s->prims[1], 0, 0, 0, 0.6, 0.25, 0.6, NULL);
         make_box(&s->prims[2], 0, -0.5, 0, 0.3, 0.25, 0.3, NULL);
         break;
-    default:
-        return NULL; /* SDF operators / Mandelbulb: SURVEY 8(f) N4 */
+    case 6: /* "Rounded Box", sceneManager.ts:178-186 */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_wrap(OP_ROUND, mk_box(0, 0, 0, 0.4, 0.4, 0.4, NULL), 0.3);
+        break;
+    case 10: /* "Smooth Union" */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_smooth(OP_SMOOTH_UNION, mk_sphere(0, 0, 0, 0.5, NULL), mk_box(0, 0.5, 0, 1, 0.2, 1, NULL), 0.2);
+        break;
+    case 11: { /* "Smooth Subtraction" */
+        const float rot[3] = {0.0f, f32(3.141592653589793 / 4), 0.0f};
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_smooth(OP_SMOOTH_SUB, mk_wrap(OP_ROUND, mk_box(0, 0, 0, 1, 1, 1, rot), 0.1),
+                                mk_sphere(0, 0, 0, 0.9, NULL), 0.2);
+        break;
+    }
+    case 12: /* "Smooth Union [A]" */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_smooth(OP_SMOOTH_UNION, mk_anim(mk_sphere(0, 0, 0, 1, NULL), 1, 0, 0, 3.0, 0.005),
+                                mk_sphere(0, 0, 0, 1, NULL), 0.2);
+        break;
+    case 13: /* "Mandelbulb [A]" */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_mandelbulb(0, 0, 0, 8, 80, 1, -0.0001, NULL);
+        break;
+    case 14: { /* "Twisted Torus" */
+        const float rot[3] = {f32(-3.141592653589793 / 2), 0.0f, 0.0f};
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_wrap(OP_TWIST, mk_torus(0, 0, 0, 1.3, rot), 3);
+        break;
+    }
+    case 15: /* "Infinite Spheres" */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_repetition(mk_sphere(0, 0, 0, 0.3, NULL), 1.5, 1.5, 1.5);
+        break;
+    case 16: /* "Screw" */
+        s = scene_alloc(1, accel);
+        s->prims[0] = mk_wrap(OP_ROUND, mk_wrap(OP_TWIST, mk_box(0, 0, 0, 0.4, 1.5, 0.4, NULL), 4.0), 0.1);
+        break;
+    case 17: { /* "Chicken": a left-nested chain of nine smooth unions over ten boxes */
+        static const double b[10][6] = {
+            {0, 0, 0, 0.6, 0.6, 0.8}, {0, -0.2, 0, 0.8, 0.4, 0.6}, {0, -0.8, 0.8, 0.4, 0.6, 0.3},
+            {0, -0.8, 1.2, 0.4, 0.2, 0.2}, {0, -0.4, 1.0, 0.2, 0.2, 0.2}, {0.3, 1, 0, 0.1, 0.6, 0.01},
+            {-0.3, 1, 0, 0.1, 0.6, 0.01}, {0, 1.6, 0.2, 0.6, 0.01, 0.2}, {0.3, 1.6, 0.5, 0.1, 0.01, 0.1},
+            {-0.3, 1.6, 0.5, 0.1, 0.01, 0.1}};
+        s = scene_alloc(1, accel);
+        Prim acc = mk_box(b[0][0], b[0][1], b[0][2], b[0][3], b[0][4], b[0][5], NULL);
+        for (int i = 1; i < 10; i++)
+            acc = mk_smooth(OP_SMOOTH_UNION, acc, mk_box(b[i][0], b[i][1], b[i][2], b[i][3], b[i][4], b[i][5], NULL), 0.0001);
+        s->prims[0] = acc;
+        break;
+    }
+    default: { /* 18: "67" */
+        const double PI = 3.141592653589793;
+        const float r5[3] = {0.0f, 0.0f, f32(PI / 5)}, r7[3] = {0.0f, 0.0f, f32(PI / 7)}, r2[3] = {0.0f, 0.0f, f32(PI / 2)};
+        const float rt[3] = {f32(-PI / 2), 0.0f, 0.0f};
+        s = scene_alloc(2, accel);
+        s->prims[0] = mk_smooth(OP_SMOOTH_UNION,
+                                mk_wrap(OP_ROUND, mk_box(-1.25, -0.8, 0, 0.05, 0.7, 0.05, r5), 0.20),
+                                mk_wrap(OP_ROUND, mk_torus(-1.25, 0.5, 0, 0.8, rt), 0.05), 0.0001);
+        s->prims[1] = mk_smooth(OP_SMOOTH_UNION,
+                                mk_wrap(OP_ROUND, mk_box(1.35, 0, 0, 0.05, 1.5, 0.05, r7), 0.20),
+                                mk_wrap(OP_ROUND, mk_box(1.25, -1.4, 0, 0.05, 0.8, 0.05, r2), 0.20), 0.0001);
+        break;
+    }
     }
     scene_build_accel(s);
     return s;
@@ -911,6 +1170,91 @@ ro_scene *ro_scene_from_prims(const double *desc, int n, const char *accel) {
     return s;
 }
 
+/* Build-defined generic entry for tests: an expression forest.  16 doubles per node:
+ * {type, x, y, z, rotX, rotY, rotZ (NaN rotX = no rotation argument), p0..p5, a, b, unused};
+ * leaves take position/rotation and p0.. as in ro_scene_from_prims (Mandelbulb: power,
+ * iterations, enableAnimation, animationSpeed); operators take operand node indices a (and b):
+ * Round p0 = radius; SmoothUnion/SmoothSubtraction p0 = smoothness; Twist p0 = amount;
+ * Repetition p0..p2 = spacing; AnimatedTranslate p0..p2 = direction, p3 = amplitude, p4 = speed.
+ * roots[] lists the nodes that are Scene.objects, in order. */
+static Prim node_build(const double *desc, int idx) {
+    const double *d = desc + 16 * idx;
+    float rot[3] = {f32(d[4]), f32(d[5]), f32(d[6])};
+    const float *r = (d[4] != d[4]) ? NULL : rot;
+    const int type = (int)d[0];
+    switch (type) {
+    case PRIM_BOX: return mk_box(d[1], d[2], d[3], d[7], d[8], d[9], r);
+    case PRIM_TORUS: return mk_torus(d[1], d[2], d[3], d[7], r);
+    case PRIM_MANDELBULB: return mk_mandelbulb(d[1], d[2], d[3], d[7], (int)d[8], d[9] != 0, d[10], r);
+    case OP_ROUND: case OP_TWIST: return mk_wrap(type, node_build(desc, (int)d[13]), d[7]);
+    case OP_REPETITION: return mk_repetition(node_build(desc, (int)d[13]), d[7], d[8], d[9]);
+    case OP_ANIM: return mk_anim(node_build(desc, (int)d[13]), d[7], d[8], d[9], d[10], d[11]);
+    case OP_SMOOTH_UNION: case OP_SMOOTH_SUB:
+        return mk_smooth(type, node_build(desc, (int)d[13]), node_build(desc, (int)d[14]), d[7]);
+    default: return mk_sphere(d[1], d[2], d[3], d[7], r);
+    }
+}
+ro_scene *ro_scene_from_nodes(const double *desc, int n_nodes, const int *roots, int n_roots, const char *accel) {
+    (void)n_nodes;
+    ro_scene *s = scene_alloc(n_roots, accel);
+    for (int i = 0; i < n_roots; i++) s->prims[i] = node_build(desc, roots[i]);
+    scene_build_accel(s);
+    return s;
+}
+
+/* Flattened expression forest as the product's rm_scene_from_nodes takes it: per node type,
+ * operand indices, the world->local matrix (16 f32) and 6 doubles of parameters (layout of
+ * rm_node.params in include/rm_raymarch.h).  Returns the node count; call with NULL buffers to size. */
+static int flatten(const Prim *p, int *types, int *kids, float *transforms, double *params, int *n) {
+    int ia = -1, ib = -1;
+    if (p->a) ia = flatten(p->a, types, kids, transforms, params, n);
+    if (p->b) ib = flatten(p->b, types, kids, transforms, params, n);
+    const int me = (*n)++;
+    if (types) {
+        types[me] = p->type; kids[2 * me] = ia; kids[2 * me + 1] = ib;
+        memcpy(transforms + 16 * me, p->transform, 16 * sizeof(float));
+        double *q = params + 6 * me;
+        for (int i = 0; i < 6; i++) q[i] = 0;
+        switch (p->type) {
+        case PRIM_SPHERE: q[0] = p->radius; break;
+        case PRIM_BOX: q[0] = p->halfSize[0]; q[1] = p->halfSize[1]; q[2] = p->halfSize[2]; break;
+        case PRIM_TORUS: q[0] = p->majorRadius; q[1] = p->minorRadius; break;
+        case PRIM_MANDELBULB: q[0] = p->power; q[1] = p->iterations; q[2] = p->enableAnimation; q[3] = p->speed; break;
+        case OP_REPETITION: q[0] = p->vec[0]; q[1] = p->vec[1]; q[2] = p->vec[2]; break;
+        case OP_ANIM: q[0] = p->vec[0]; q[1] = p->vec[1]; q[2] = p->vec[2]; q[3] = p->k; q[4] = p->speed; break;
+        default: q[0] = p->k; break;
+        }
+    }
+    return me;
+}
+int ro_scene_nodes(const ro_scene *s, int *types, int *kids, float *transforms, double *params, int *roots) {
+    int n = 0;
+    for (int i = 0; i < s->n; i++) {
+        int r = flatten(&s->prims[i], types, kids, transforms, params, &n);
+        if (roots) roots[i] = r;
+    }
+    return n;
+}
+
+/* ro_jsmath.h entry for tests: fn 0 sin, 1 cos, 2 atan2(a,b), 3 asin, 4 log, 5 pow(a,b), 6 round, 7 atan */
+void ro_jsmath_eval(int fn, const double *a, const double *b, double *out, long n) {
+    for (long i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: out[i] = js_sin(a[i]); break;
+        case 1: out[i] = js_cos(a[i]); break;
+        case 2: out[i] = js_atan2(a[i], b[i]); break;
+        case 3: out[i] = js_asin(a[i]); break;
+        case 4: out[i] = js_log(a[i]); break;
+        case 5: out[i] = js_pow(a[i], b[i]); break;
+        case 6: out[i] = js_round(a[i]); break;
+        default: out[i] = js_atan(a[i]); break;
+        }
+    }
+}
+
+/* Scene.updateTime for ro_scene_distance (renders take `time` as an argument) */
+void ro_set_time(double t) { g_time = t; }
+
 /* per primitive: type, world->local transform (16 f32), params (3 doubles) -- what the product's
  * rm_scene_from_prims takes */
 void ro_scene_prims(const ro_scene *s, int *types, float *transforms, double *params) {
@@ -927,6 +1271,7 @@ void ro_scene_prims(const ro_scene *s, int *types, float *transforms, double *pa
 void ro_scene_free(ro_scene *s) {
     if (!s) return;
     bvh_free(s->bvh); oct_free(s->octree);
+    for (int i = 0; i < s->n; i++) prim_free_children(&s->prims[i]);
     free(s->primBounds); free(s->prims); free(s);
 }
 
@@ -1221,7 +1566,7 @@ int ro_run_raymarcher_ex(const ro_scene *s, const char *algorithm, uint8_t *dept
                          uint8_t *normalBuffer, uint16_t *sdfBuffer, uint16_t *iterBuffer,
                          int width, int height, double time, int yStart, int yEnd,
                          double overshootFactor, double stepSize) {
-    (void)time; /* scene.updateTime: no animated primitives among spheres */
+    g_time = time; /* raymarcher.ts:58-59 scene.updateTime(time) */
     const int alg = parse_algorithm(algorithm);
     if (overshootFactor != overshootFactor) overshootFactor = 1.2;
     if (stepSize != stepSize) stepSize = 0.1;

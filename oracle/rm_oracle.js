@@ -17,6 +17,7 @@
  * usage: node rm_oracle.js render <config.json> <outdir>
  *        node rm_oracle.js hypot  <in.f64 triples> <out.f64>
  *        node rm_oracle.js camera <in.f64 pitch,yaw pairs> <out.f32 x12>
+ *        node rm_oracle.js jsmath <fn 0..8> <a.f64> <b.f64> <out.f64>   (the engine's Math.*; 8 = the fdlibm pow port)
  */
 const fs = require('fs');
 const path = require('path');
@@ -103,27 +104,63 @@ function m4rotZ(a, rad) { // mat4.rotateZ into a fresh matrix
 
 // desc: [x, y, z, r] (sphere, no rotation argument) or
 //       {type: 'sphere'|'box'|'torus', pos: [x,y,z], rot: Float32Array(3)|undefined, r | half | radius}
+const OPS = { round: 1, twist: 1, repetition: 1, anim: 1, smoothUnion: 2, smoothSub: 2 };
+function finishBounds(q, localRadius) { // boundingBox.ts:133-154
+  const back = m4identity(); const ok = m4invert(back, q.T);
+  const m = ok ? back : q.T;
+  const sc = Math.max(Math.hypot(m[0], m[1], m[2]), Math.hypot(m[4], m[5], m[6]), Math.hypot(m[8], m[9], m[10]));
+  q.localRadius = localRadius;
+  q.back = back; // what mat4.invert(localToWorld, this.transform) yields inside the operators
+  const pad = localRadius * sc * 1.5, c = q.c;
+  q.lo = new Float32Array([c[0] - pad, c[1] - pad, c[2] - pad]);
+  q.hi = new Float32Array([c[0] + pad, c[1] + pad, c[2] + pad]);
+  return q;
+}
 function makePrim(desc) {
   if (Array.isArray(desc)) desc = { type: 'sphere', pos: [desc[0], desc[1], desc[2]], r: desc[3] };
+  if (OPS[desc.type]) { // primitive_operations/*.ts
+    const a = makePrim(desc.a), b = OPS[desc.type] === 2 ? makePrim(desc.b) : null;
+    const q = { type: desc.type, a, b };
+    if (b) { // smoothUnion.ts / smoothSubstraction.ts: identity transform
+      q.T = m4identity(); q.k = desc.k;
+      if (desc.type === 'smoothUnion') {
+        q.c = new Float32Array([(a.c[0] + b.c[0]) / 2, (a.c[1] + b.c[1]) / 2, (a.c[2] + b.c[2]) / 2]);
+        const dist = Math.hypot(b.c[0] - a.c[0], b.c[1] - a.c[1], b.c[2] - a.c[2]);
+        return finishBounds(q, Math.max(a.localRadius, b.localRadius) + dist * 0.5);
+      }
+      q.c = a.c;
+      return finishBounds(q, a.localRadius);
+    }
+    q.T = a.T; q.c = a.c;
+    if (desc.type === 'round') { q.k = desc.radius; return finishBounds(q, a.localRadius + desc.radius); }
+    if (desc.type === 'twist') { q.k = desc.amount; return finishBounds(q, a.localRadius); }
+    if (desc.type === 'repetition') { q.spacing = new Float32Array(desc.spacing); return finishBounds(q, Infinity); }
+    const d = new Float32Array(desc.direction); // animatedTranslate.ts:22-23 vec3.normalize
+    let len = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (len > 0) len = 1 / Math.sqrt(len);
+    q.dir = new Float32Array([d[0] * len, d[1] * len, d[2] * len]);
+    q.amplitude = desc.amplitude; q.speed = desc.speed;
+    return finishBounds(q, a.localRadius + desc.amplitude);
+  }
   let model;
   if (desc.rot) { // sceneManager.ts:24-29: fromTranslation, rotateX, rotateY, rotateZ
     model = m4identity(); model[12] = desc.pos[0]; model[13] = desc.pos[1]; model[14] = desc.pos[2];
     model = m4rotZ(m4rotY(m4rotX(model, desc.rot[0]), desc.rot[1]), desc.rot[2]);
   } else model = m4fromRTS([0, 0, 0, 1], desc.pos, [1, 1, 1]);
   const T = m4identity(); m4invert(T, model);
-  const back = m4identity(); const ok = m4invert(back, T);
+  if (desc.type === 'mandelbulb') { // sceneManager.ts:63 mat4.scale(transform, transform, [.5,.5,.5])
+    for (let k = 0; k < 12; k++) T[k] = T[k] * 0.5;
+  }
+  const back = m4identity(); m4invert(back, T);
   const c = new Float32Array([back[12], back[13], back[14]]);
-  const m = ok ? back : T;
-  const sc = Math.max(Math.hypot(m[0], m[1], m[2]), Math.hypot(m[4], m[5], m[6]), Math.hypot(m[8], m[9], m[10]));
   const q = { T, c, type: desc.type };
   let localRadius;
   if (desc.type === 'box') { q.half = new Float32Array(desc.half); localRadius = Math.hypot(q.half[0], q.half[1], q.half[2]); }
   else if (desc.type === 'torus') { q.major = desc.radius; q.minor = desc.radius / 4; localRadius = q.major + q.minor; }
-  else { q.r = desc.r; localRadius = q.r; }
-  const pad = localRadius * sc * 1.5;
-  q.lo = new Float32Array([c[0] - pad, c[1] - pad, c[2] - pad]);
-  q.hi = new Float32Array([c[0] + pad, c[1] + pad, c[2] + pad]);
-  return q;
+  else if (desc.type === 'mandelbulb') {
+    q.power = desc.power; q.iterations = desc.iterations; q.animate = !!desc.animate; q.speed = desc.speed; localRadius = 2.5;
+  } else { q.r = desc.r; localRadius = q.r; }
+  return finishBounds(q, localRadius);
 }
 
 function presetSpheres(index) {
@@ -142,7 +179,31 @@ function presetSpheres(index) {
   else if (i === 8) out.push([-0.7, 0, 0, 0.5], { type: 'box', pos: [1, 0, 0], half: [0.5, 0.5, 0.5] });
   else if (i === 9) out.push({ type: 'box', pos: [0, 0.5, 0], half: [0.9, 0.25, 0.9] }, { type: 'box', pos: [0, 0, 0], half: [0.6, 0.25, 0.6] },
     { type: 'box', pos: [0, -0.5, 0], half: [0.3, 0.25, 0.3] });
-  else throw new Error('preset ' + i + ' needs SDF operators / Mandelbulb (out of scope)');
+  else {
+    const PI = Math.PI, f3 = (x, y, z) => new Float32Array([x, y, z]);
+    const box = (x, y, z, half, rot) => ({ type: 'box', pos: [x, y, z], half, rot });
+    const sph = (x, y, z, r) => ({ type: 'sphere', pos: [x, y, z], r });
+    const tor = (x, y, z, radius, rot) => ({ type: 'torus', pos: [x, y, z], radius, rot });
+    const round = (a, radius) => ({ type: 'round', a, radius });
+    const su = (a, b, k) => ({ type: 'smoothUnion', a, b, k });
+    if (i === 6) out.push(round(box(0, 0, 0, [0.4, 0.4, 0.4]), 0.3));
+    else if (i === 10) out.push(su(sph(0, 0, 0, 0.5), box(0, 0.5, 0, [1, 0.2, 1]), 0.2));
+    else if (i === 11) out.push({ type: 'smoothSub', a: round(box(0, 0, 0, [1, 1, 1], f3(0, PI / 4, 0)), 0.1), b: sph(0, 0, 0, 0.9), k: 0.2 });
+    else if (i === 12) out.push(su({ type: 'anim', a: sph(0, 0, 0, 1), direction: [1, 0, 0], amplitude: 3.0, speed: 0.005 }, sph(0, 0, 0, 1), 0.2));
+    else if (i === 13) out.push({ type: 'mandelbulb', pos: [0, 0, 0], power: 8, iterations: 80, animate: true, speed: -0.0001 });
+    else if (i === 14) out.push({ type: 'twist', a: tor(0, 0, 0, 1.3, f3(-PI / 2, 0, 0)), amount: 3 });
+    else if (i === 15) out.push({ type: 'repetition', a: sph(0, 0, 0, 0.3), spacing: [1.5, 1.5, 1.5] });
+    else if (i === 16) out.push(round({ type: 'twist', a: box(0, 0, 0, [0.4, 1.5, 0.4]), amount: 4.0 }, 0.1));
+    else if (i === 17) {
+      const b = [[0, 0, 0, 0.6, 0.6, 0.8], [0, -0.2, 0, 0.8, 0.4, 0.6], [0, -0.8, 0.8, 0.4, 0.6, 0.3], [0, -0.8, 1.2, 0.4, 0.2, 0.2],
+        [0, -0.4, 1.0, 0.2, 0.2, 0.2], [0.3, 1, 0, 0.1, 0.6, 0.01], [-0.3, 1, 0, 0.1, 0.6, 0.01], [0, 1.6, 0.2, 0.6, 0.01, 0.2],
+        [0.3, 1.6, 0.5, 0.1, 0.01, 0.1], [-0.3, 1.6, 0.5, 0.1, 0.01, 0.1]].map(v => box(v[0], v[1], v[2], [v[3], v[4], v[5]]));
+      out.push(b.slice(1).reduce((acc, x) => su(acc, x, 0.0001), b[0]));
+    } else {
+      out.push(su(round(box(-1.25, -0.8, 0, [0.05, 0.7, 0.05], f3(0, 0, PI / 5)), 0.20), round(tor(-1.25, 0.5, 0, 0.8, f3(-PI / 2, 0, 0)), 0.05), 0.0001));
+      out.push(su(round(box(1.35, 0, 0, [0.05, 1.5, 0.05], f3(0, 0, PI / 7)), 0.20), round(box(1.25, -1.4, 0, [0.05, 0.8, 0.05], f3(0, 0, PI / 2)), 0.20), 0.0001));
+    }
+  }
   return out;
 }
 
@@ -306,12 +367,214 @@ function octSkip(O, o, d, t) { // octree.ts:252-278 + 195-220
 }
 
 // ---------------------------------------------------------------- scene distance
-function sphereSdf(q, p, useSqrt) { // primitive.ts:33-39, sphere.ts:12-14
+// Math.pow is the one transcendental whose node-12 (V8 7.8) value is not the fdlibm one that
+// current V8 computes (ieee754::legacy::pow); e_pow.c is therefore restated here as well.
+const _f64 = new Float64Array(1), _u32 = new Uint32Array(_f64.buffer);
+function hiWord(x) { _f64[0] = x; return _u32[1] | 0; }
+function loWord(x) { _f64[0] = x; return _u32[0] >>> 0; }
+function withLo(x, lo) { _f64[0] = x; _u32[0] = lo; return _f64[0]; }
+function withHi(x, hi) { _f64[0] = x; _u32[1] = hi; return _f64[0]; }
+function fromWords(hi, lo) { _u32[1] = hi; _u32[0] = lo; return _f64[0]; }
+function fdlibmPow(x, y) {
+  const bp = [1.0, 1.5], dp_h = [0.0, 5.84962487220764160156e-01], dp_l = [0.0, 1.35003920212974897128e-08];
+  const two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300,
+    L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
+    L4 = 2.72728123808534006489e-01, L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+    P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+    P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+    lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01, lg2_l = -1.90465429995776804525e-09,
+    ovt = 8.0085662595372944372e-0017, cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+    cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00, ivln2_h = 1.44269502162933349609e+00,
+    ivln2_l = 1.92596299112661746887e-08;
+  const hx = hiWord(x), lx = loWord(x), hy = hiWord(y), ly = loWord(y);
+  let ix = hx & 0x7fffffff; const iy = hy & 0x7fffffff;
+  if ((iy | ly) === 0) return 1.0;
+  if (ix > 0x7ff00000 || (ix === 0x7ff00000 && lx !== 0) || iy > 0x7ff00000 || (iy === 0x7ff00000 && ly !== 0)) return x + y;
+  let yisint = 0, k, j, n, i;
+  if (hx < 0) {
+    if (iy >= 0x43400000) yisint = 2;
+    else if (iy >= 0x3ff00000) {
+      k = (iy >> 20) - 0x3ff;
+      if (k > 20) { j = ly >>> (52 - k); if (((j << (52 - k)) >>> 0) === ly) yisint = 2 - (j & 1); }
+      else if (ly === 0) { j = iy >> (20 - k); if ((j << (20 - k)) === iy) yisint = 2 - (j & 1); }
+    }
+  }
+  if (ly === 0) {
+    if (iy === 0x7ff00000) {
+      if (((ix - 0x3ff00000) | lx) === 0) return y - y;
+      else if (ix >= 0x3ff00000) return (hy >= 0) ? y : 0.0;
+      else return (hy < 0) ? -y : 0.0;
+    }
+    if (iy === 0x3ff00000) return (hy < 0) ? 1.0 / x : x;
+    if (hy === 0x40000000) return x * x;
+    if (hy === 0x3fe00000) { if (hx >= 0) return Math.sqrt(x); }
+  }
+  let ax = Math.abs(x), z;
+  if (lx === 0) {
+    if (ix === 0x7ff00000 || ix === 0 || ix === 0x3ff00000) {
+      z = ax;
+      if (hy < 0) z = 1.0 / z;
+      if (hx < 0) {
+        if (((ix - 0x3ff00000) | yisint) === 0) z = (z - z) / (z - z);
+        else if (yisint === 1) z = -z;
+      }
+      return z;
+    }
+  }
+  n = (hx >> 31) + 1;
+  if ((n | yisint) === 0) return (x - x) / (x - x);
+  let s = 1.0;
+  if ((n | (yisint - 1)) === 0) s = -1.0;
+  let t, u, v, w, t1, t2, r, p_h, p_l, z_h, z_l;
+  if (iy > 0x41e00000) {
+    if (iy > 0x43f00000) {
+      if (ix <= 0x3fefffff) return (hy < 0) ? huge * huge : tiny * tiny;
+      if (ix >= 0x3ff00000) return (hy > 0) ? huge * huge : tiny * tiny;
+    }
+    if (ix < 0x3fefffff) return (hy < 0) ? s * huge * huge : s * tiny * tiny;
+    if (ix > 0x3ff00000) return (hy > 0) ? s * huge * huge : s * tiny * tiny;
+    t = ax - 1.0;
+    w = (t * t) * (0.5 - t * (0.3333333333333333333333 - t * 0.25));
+    u = ivln2_h * t;
+    v = t * ivln2_l - w * ivln2;
+    t1 = withLo(u + v, 0);
+    t2 = v - (t1 - u);
+  } else {
+    n = 0;
+    if (ix < 0x00100000) { ax *= two53; n -= 53; ix = hiWord(ax); }
+    n += (ix >> 20) - 0x3ff;
+    j = ix & 0x000fffff;
+    ix = j | 0x3ff00000;
+    if (j <= 0x3988E) k = 0;
+    else if (j < 0xBB67A) k = 1;
+    else { k = 0; n += 1; ix -= 0x00100000; }
+    ax = withHi(ax, ix);
+    u = ax - bp[k];
+    v = 1.0 / (ax + bp[k]);
+    const ss = u * v;
+    const s_h = withLo(ss, 0);
+    let t_h = fromWords(((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18), 0);
+    let t_l = ax - (t_h - bp[k]);
+    const s_l = v * ((u - s_h * t_h) - s_h * t_l);
+    let s2 = ss * ss;
+    r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+    r += s_l * (s_h + ss);
+    s2 = s_h * s_h;
+    t_h = withLo(3.0 + s2 + r, 0);
+    t_l = r - ((t_h - 3.0) - s2);
+    u = s_h * t_h;
+    v = s_l * t_h + t_l * ss;
+    p_h = withLo(u + v, 0);
+    p_l = v - (p_h - u);
+    z_h = cp_h * p_h;
+    z_l = cp_l * p_h + p_l * cp + dp_l[k];
+    t = n;
+    t1 = withLo(((z_h + z_l) + dp_h[k]) + t, 0);
+    t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+  }
+  const y1 = withLo(y, 0);
+  p_l = (y - y1) * t1 + y * t2;
+  p_h = y1 * t1;
+  z = p_l + p_h;
+  j = hiWord(z); i = loWord(z) | 0;
+  if (j >= 0x40900000) {
+    if (((j - 0x40900000) | i) !== 0) return s * huge * huge;
+    if (p_l + ovt > z - p_h) return s * huge * huge;
+  } else if ((j & 0x7fffffff) >= 0x4090cc00) {
+    if (((j - (0xc090cc00 | 0)) | i) !== 0) return s * tiny * tiny;
+    if (p_l <= z - p_h) return s * tiny * tiny;
+  }
+  i = j & 0x7fffffff;
+  k = (i >> 20) - 0x3ff;
+  n = 0;
+  if (i > 0x3fe00000) {
+    n = (j + (0x00100000 >> (k + 1))) | 0;
+    k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+    t = fromWords(n & ~(0x000fffff >> k), 0);
+    n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+    if (j < 0) n = -n;
+    p_h -= t;
+  }
+  t = withLo(p_l + p_h, 0);
+  u = t * lg2_h;
+  v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+  z = u + v;
+  w = v - (z - u);
+  t = z * z;
+  t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  r = (z * t1) / (t1 - 2.0) - (w + z * w);
+  z = 1.0 - (r - z);
+  j = hiWord(z);
+  j = (j + (n << 20)) | 0;
+  if ((j >> 20) <= 0) { // scalbn(z, n), n < 0: subnormal result; one rounding, at the last multiplication
+    let e = n;
+    if (e < -1022) { z *= fromWords((0x3ff - 969) << 20, 0); e += 969; if (e < -1022) { z *= fromWords((0x3ff - 969) << 20, 0); e += 969; if (e < -1022) e = -1022; } }
+    z = z * fromWords((0x3ff + e) << 20, 0);
+  }
+  else z = withHi(z, j);
+  return s * z;
+}
+
+let gTime = 0; // Scene.updateTime (scene.ts:135-140)
+function xform(m, x, y, z, out) { // vec3.transformMat4
+  let w = m[3] * x + m[7] * y + m[11] * z + m[15]; w = w || 1.0;
+  out[0] = (m[0] * x + m[4] * y + m[8] * z + m[12]) / w;
+  out[1] = (m[1] * x + m[5] * y + m[9] * z + m[13]) / w;
+  out[2] = (m[2] * x + m[6] * y + m[10] * z + m[14]) / w;
+  return out;
+}
+function mandelbulbSdf(q, lx, ly, lz, useSqrt) { // mandelbulb.ts:37-78
+  const p = new Float32Array([lx, lz, ly]), z = new Float32Array(p);
+  let dr = 1.0, r = 0.0;
+  for (let i = 0; i < q.iterations; i++) {
+    r = useSqrt ? Math.sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) : Math.hypot(z[0], z[1], z[2]);
+    if (r > 2.0) break;
+    let theta = Math.atan2(z[1], z[0]);
+    let phi = Math.asin(z[2] / r);
+    if (q.animate) phi += gTime * q.speed;
+    dr = fdlibmPow(r, q.power - 1.0) * dr * q.power + 1.0;
+    r = fdlibmPow(r, q.power);
+    theta = theta * q.power;
+    phi = phi * q.power;
+    z[0] = r * Math.cos(theta) * Math.cos(phi) + p[0];
+    z[1] = r * Math.sin(theta) * Math.cos(phi) + p[1];
+    z[2] = r * Math.sin(phi) + p[2];
+  }
+  return 0.5 * Math.log(r) * r / dr;
+}
+function opSdf(q, lx, ly, lz, useSqrt) { // primitive_operations/*.ts localSdf
+  if (q.type === 'anim') { // animatedTranslate.ts:34-49
+    const offset = Math.sin(gTime * q.speed) * q.amplitude;
+    const off = new Float32Array([q.dir[0] * offset, q.dir[1] * offset, q.dir[2] * offset]);
+    const adj = new Float32Array([lx - off[0], ly - off[1], lz - off[2]]);
+    return sphereSdf(q.a, adj, useSqrt);
+  }
+  const w = xform(q.back, lx, ly, lz, new Float32Array(3));
+  if (q.type === 'round') return sphereSdf(q.a, w, useSqrt) - q.k;
+  if (q.type === 'twist') {
+    const c = Math.cos(q.k * w[1]), s = Math.sin(q.k * w[1]);
+    return sphereSdf(q.a, new Float32Array([c * w[0] - s * w[2], w[1], s * w[0] + c * w[2]]), useSqrt);
+  }
+  if (q.type === 'repetition') {
+    const sp = q.spacing;
+    const r = new Float32Array([w[0] - sp[0] * Math.round(w[0] / sp[0]), w[1] - sp[1] * Math.round(w[1] / sp[1]),
+      w[2] - sp[2] * Math.round(w[2] / sp[2])]);
+    return sphereSdf(q.a, r, useSqrt);
+  }
+  const d1 = sphereSdf(q.a, w, useSqrt), d2 = sphereSdf(q.b, w, useSqrt), k = q.k * 4.0;
+  if (q.type === 'smoothUnion') { const h = Math.max(k - Math.abs(d1 - d2), 0.0); return Math.min(d1, d2) - h * h * 0.25 / k; }
+  const h = Math.max(k - Math.abs(d1 + d2), 0.0);
+  return Math.max(d1, -d2) + h * h * 0.25 / k;
+}
+
+function sphereSdf(q, p, useSqrt) { // primitive.ts:33-39 + every class's localSdf
   const m = q.T, x = p[0], y = p[1], z = p[2];
   let w = m[3] * x + m[7] * y + m[11] * z + m[15]; w = w || 1.0;
   const lx = fr((m[0] * x + m[4] * y + m[8] * z + m[12]) / w);
   const ly = fr((m[1] * x + m[5] * y + m[9] * z + m[13]) / w);
   const lz = fr((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
+  if (OPS[q.type]) return opSdf(q, lx, ly, lz, useSqrt);
+  if (q.type === 'mandelbulb') return mandelbulbSdf(q, lx, ly, lz, useSqrt);
   if (q.type === 'box') { // box.ts:13-30
     const e = new Float32Array([Math.abs(lx) - q.half[0], Math.abs(ly) - q.half[1], Math.abs(lz) - q.half[2]]);
     const out = new Float32Array([Math.max(e[0], 0), Math.max(e[1], 0), Math.max(e[2], 0)]);
@@ -565,13 +828,21 @@ function cmdRender(cfgPath, outDir) {
     spheres = [];
     for (let i = 0; i + 3 < f.length; i += 4) spheres.push([f[i], f[i + 1], f[i + 2], f[i + 3]]);
   } else if (cfg.prims) {
-    spheres = cfg.prims.map(d => ({ type: d.type, pos: d.pos, rot: d.rot ? new Float32Array(d.rot) : undefined, r: d.r, half: d.half, radius: d.radius }));
+    const conv = d => {
+      const o = Object.assign({}, d);
+      if (d.rot) o.rot = new Float32Array(d.rot); else delete o.rot;
+      if (d.a) o.a = conv(d.a);
+      if (d.b) o.b = conv(d.b);
+      return o;
+    };
+    spheres = cfg.prims.map(conv);
   } else spheres = presetSpheres(cfg.preset);
   const S = makeScene(spheres, cfg.accel, cfg.length_sqrt);
   const cam = cameraMatrix(cfg.pitch || 0, cfg.yaw || 0);
   const W = cfg.width, H = cfg.height;
   const y0 = cfg.yStart === undefined ? 0 : cfg.yStart, y1 = cfg.yEnd === undefined ? H : cfg.yEnd;
   const t0 = process.hrtime.bigint();
+  gTime = cfg.time || 0; // raymarcher.ts:58-59 scene.updateTime(time)
   const r = renderTile(S, cam, W, H, y0, y1, cfg.algorithm, cfg.overshootFactor, cfg.stepSize);
   const t1 = process.hrtime.bigint();
   const rgba = shade(cfg.shader || 'normal', r.depth, r.normal, r.sdf, r.iters, W, y1 - y0);
@@ -613,8 +884,18 @@ function cmdCamera(inPath, outPath) {
   fs.writeFileSync(outPath, Buffer.from(out.buffer));
 }
 
-const [cmd, a1, a2] = process.argv.slice(2);
+function cmdJsMath(fn, aPath, bPath, outPath) {
+  const rd = f => { const raw = fs.readFileSync(f); return new Float64Array(raw.buffer, raw.byteOffset, raw.byteLength / 8); };
+  const A = rd(aPath), B = rd(bPath), out = new Float64Array(A.length);
+  const f = [a => Math.sin(a), a => Math.cos(a), (a, b) => Math.atan2(a, b), a => Math.asin(a), a => Math.log(a),
+    (a, b) => Math.pow(a, b), a => Math.round(a), a => Math.atan(a), (a, b) => fdlibmPow(a, b)][+fn];
+  for (let i = 0; i < A.length; i++) out[i] = f(A[i], B[i]);
+  fs.writeFileSync(outPath, Buffer.from(out.buffer));
+}
+
+const [cmd, a1, a2, a3, a4] = process.argv.slice(2);
 if (cmd === 'render') cmdRender(a1, a2);
+else if (cmd === 'jsmath') cmdJsMath(a1, a2, a3, a4);
 else if (cmd === 'hypot') cmdHypot(a1, a2);
 else if (cmd === 'camera') cmdCamera(a1, a2);
-else { process.stderr.write('usage: node rm_oracle.js render|hypot|camera ...\n'); process.exit(2); }
+else { process.stderr.write('usage: node rm_oracle.js render|hypot|camera|jsmath ...\n'); process.exit(2); }

@@ -42,6 +42,16 @@ WORKLOADS = {
     "N3mixed": dict(name="N3: 40 synthetic mixed primitives (spheres, boxes, tori, rotated), 3840x2160, "
                          "sphere-tracing + BVH, Phong shader",
                     mixed=40, accel="BVH", width=3840, height=2160, shader="phong"),
+    # SDF operators / Mandelbulb through the expression-program interpreter
+    "N4chicken": dict(name="N4: Chicken (preset 17: nine nested smooth unions over ten boxes), 3840x2160, "
+                           "sphere-tracing + BVH, Phong shader",
+                      preset=17, accel="BVH", width=3840, height=2160, shader="phong"),
+    "N4screw": dict(name="N4: Screw (preset 16: Round(Twist(Box)), Math.sin/cos per evaluation), 3840x2160, "
+                         "sphere-tracing + BVH, Phong shader",
+                    preset=16, accel="BVH", width=3840, height=2160, shader="phong"),
+    "N4mandelbulb": dict(name="N4: Mandelbulb (preset 13: 80 escape iterations with atan2/asin/pow/sin/cos/log), "
+                              "1920x1080, sphere-tracing + BVH, iteration-heatmap shader",
+                         preset=13, accel="BVH", width=1920, height=1080, shader="iteration-heatmap"),
 }
 
 

@@ -9,7 +9,7 @@ from ._native import RmError, RmUnsupported, RM_SCENE_UPLOADED
 
 _native.lib()  # raise now, not at first render, when the HIP library is missing
 
-from .context import Context, camera_from_angles, make_transform, partition_rows  # noqa: E402
+from .context import Context, camera_from_angles, make_transform, partition_rows, scale_transform  # noqa: E402
 from .host import (ALGORITHMS, SHADERS, AdaptiveStep, AdaptiveStepV2, AdaptiveStepV3, Camera, FixedStep,  # noqa: E402
                    IterationHeatmap, Job, NormalModel, PhongModel, Raymarcher, RaymarchWorker, Result, Scene,
                    SDFHeatmap, ShadingModel, SphereTracer, createRaymarcher, createShadingModelFromValue,

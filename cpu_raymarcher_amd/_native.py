@@ -51,6 +51,11 @@ class rm_scene_info(C.Structure):
                 ("nodes_in_lds", C.c_int32), ("reserved", C.c_int32)]
 
 
+class rm_node(C.Structure):  # include/rm_raymarch.h: struct rm_node
+    _fields_ = [("type", C.c_int32), ("child_a", C.c_int32), ("child_b", C.c_int32), ("reserved", C.c_int32),
+                ("world_to_local", C.c_float * 16), ("params", C.c_double * 6)]
+
+
 class rm_prim(C.Structure):  # include/rm_raymarch.h: struct rm_prim
     _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("world_to_local", C.c_float * 16),
                 ("params", C.c_double * 3), ("reserved2", C.c_double)]
@@ -76,6 +81,10 @@ SIGNATURES = {
     "rm_scene_from_spheres": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32]),
     "rm_scene_from_prims": (C.c_int, [_VP, C.POINTER(rm_prim), C.c_int32, C.c_int32]),
     "rm_make_transform": (C.c_int, [C.c_double, C.c_double, C.c_double, _VP, _VP]),
+    "rm_scene_from_nodes": (C.c_int, [_VP, C.POINTER(rm_node), C.c_int32, _VP, C.c_int32, C.c_int32]),
+    "rm_scale_transform": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double]),
+    "rm_scene_set_time": (C.c_int, [_VP, C.c_double]),
+    "rm_selftest_jsmath": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int64, _VP]),
     "rm_scene_get_info": (C.c_int, [_VP, C.POINTER(rm_scene_info)]),
     "rm_camera_from_angles": (C.c_int, [C.c_double, C.c_double, _VP, _VP]),
     "rm_scene_distance": (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP]),

@@ -84,6 +84,32 @@ class Context:
                 arr[i].params[k] = float(par[k]) if k < len(par) else 0.0
         N.check(self._h, N.lib().rm_scene_from_prims(self._h, arr, len(prims), int(accel)))
 
+    def scene_from_nodes(self, nodes, roots, accel):
+        """SDF expression forest (rm_scene_from_nodes): nodes = iterable of
+        (type, child_a, child_b, world_to_local[16] | None, params[<=6]); roots = Scene.objects."""
+        nodes = list(nodes)
+        arr = (N.rm_node * max(1, len(nodes)))()
+        for i, (t, a, b, m, par) in enumerate(nodes):
+            arr[i].type, arr[i].child_a, arr[i].child_b = int(t), int(a), int(b)
+            for k in range(16):
+                arr[i].world_to_local[k] = 0.0 if m is None else float(m[k])
+            for k in range(6):
+                arr[i].params[k] = float(par[k]) if k < len(par) else 0.0
+        r = np.ascontiguousarray(roots, dtype=np.int32)
+        N.check(self._h, N.lib().rm_scene_from_nodes(self._h, arr, len(nodes), _ptr(r), len(r), int(accel)))
+
+    def scene_set_time(self, time):
+        """Scene.updateTime(time) for scene_distance (renders take the job's time)."""
+        N.check(self._h, N.lib().rm_scene_set_time(self._h, float(time)))
+
+    def selftest_jsmath(self, fn, a, b=None):
+        """Math.sin/cos/atan2/asin/log/pow/round/atan (fn 0..7) as the device evaluates them."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros_like(a)
+        N.check(self._h, N.lib().rm_selftest_jsmath(self._h, int(fn), _ptr(a), _ptr(b), a.size, _ptr(out)))
+        return out
+
     def scene_info(self):
         info = N.rm_scene_info()
         N.check(self._h, N.lib().rm_scene_get_info(self._h, C.byref(info)))
@@ -182,6 +208,15 @@ def make_transform(x, y, z, rotation=None):
     rc = N.lib().rm_make_transform(float(x), float(y), float(z), _ptr(rot), _ptr(out))
     if rc != N.RM_OK:
         raise N.RmError(rc, "rm_make_transform")
+    return out
+
+
+def scale_transform(m, x, y, z):
+    """gl-matrix mat4.scale(m, m, [x, y, z]) (sceneManager.ts:63) -> new float32[16]."""
+    out = np.ascontiguousarray(m, dtype=np.float32).copy()
+    rc = N.lib().rm_scale_transform(_ptr(out), float(x), float(y), float(z))
+    if rc != N.RM_OK:
+        raise N.RmError(rc, "rm_scale_transform")
     return out
 
 

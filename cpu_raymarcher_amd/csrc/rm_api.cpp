@@ -32,6 +32,8 @@ struct DeviceScene {
     uint32_t *nn_cells = nullptr;
     uint16_t *nn_list = nullptr;
     RmPrim *prims = nullptr;
+    RmInstr *prog = nullptr;
+    int32_t *obj_ranges = nullptr;
 };
 
 }  // namespace
@@ -53,6 +55,10 @@ struct rm_ctx {
     std::vector<double> up_radii;
     std::vector<rmh::PrimDesc> up_prims;  // when the uploaded scene came from rm_scene_from_prims
     bool up_general = false;
+    std::vector<rmh::NodeDesc> up_nodes;  // when it came from rm_scene_from_nodes
+    std::vector<int> up_roots;
+    bool up_program = false;
+    double time = 0.0;  // Scene.updateTime: the last job's time, or rm_scene_set_time
 
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -108,6 +114,8 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.nn_cells);
     (void)hipFree(d.nn_list);
     (void)hipFree(d.prims);
+    (void)hipFree(d.prog);
+    (void)hipFree(d.obj_ranges);
     d = DeviceScene();
 }
 
@@ -137,6 +145,8 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.nn_cells, &ctx->dev.nn_cells))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.nn_list, &ctx->dev.nn_list))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.prims, &ctx->dev.prims))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.prog, &ctx->dev.prog))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.obj_ranges, &ctx->dev.obj_ranges))) return rc;
     return RM_OK;
 }
 
@@ -170,8 +180,33 @@ int set_scene_general(rm_ctx *ctx, const rmh::PrimDesc *prims, int n, int accel,
     return upload_scene(ctx);
 }
 
+int set_scene_nodes(rm_ctx *ctx, const rmh::NodeDesc *nodes, int n_nodes, const int *roots, int n_roots, int accel,
+                    bool uploaded, int preset) {
+    std::string err;
+    rmh::HostScene hs;
+    if (!rmh::build_scene_nodes(hs, nodes, n_nodes, roots, n_roots, accel, err)) {
+        const bool unsupported = err.find("BVH leaf") != std::string::npos || err.find("RM_PROG_MAX") != std::string::npos;
+        return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
+    }
+    hs.preset = preset;
+    ctx->host = std::move(hs);
+    ctx->have_scene = true;
+    ctx->scene_is_uploaded = uploaded;
+    ctx->scene_preset = preset;
+    return upload_scene(ctx);
+}
+
 int scene_n_prims(const rm_ctx *ctx) {
+    if (ctx->host.program) return static_cast<int>(ctx->host.obj_ranges.size() / 2);
     return static_cast<int>(ctx->host.general ? ctx->host.prims.size() : ctx->host.spheres.size());
+}
+
+// which primitive representation the kernels read (RmRenderParams::general)
+void fill_scene_repr(const rm_ctx *ctx, RmRenderParams &p) {
+    p.general = ctx->host.program ? 2 : (ctx->host.general ? 1 : 0);
+    p.prims = ctx->dev.prims;
+    p.prog = ctx->dev.prog;
+    p.obj_ranges = ctx->dev.obj_ranges;
 }
 
 int clamp_preset(int idx) { return idx < 0 ? 0 : (idx > rmh::kPresetCount - 1 ? rmh::kPresetCount - 1 : idx); }
@@ -183,6 +218,9 @@ int ensure_scene(rm_ctx *ctx, int32_t preset_index, int32_t accel_in) {
     if (preset_index == RM_SCENE_UPLOADED) {
         if (!ctx->have_uploaded) return fail(ctx, RM_E_NO_SCENE, "no scene uploaded with rm_scene_from_spheres");
         if (ctx->have_scene && ctx->scene_is_uploaded && ctx->host.accel == accel) return RM_OK;
+        if (ctx->up_program)
+            return set_scene_nodes(ctx, ctx->up_nodes.data(), static_cast<int>(ctx->up_nodes.size()), ctx->up_roots.data(),
+                                   static_cast<int>(ctx->up_roots.size()), accel, true, RM_SCENE_UPLOADED);
         if (ctx->up_general)
             return set_scene_general(ctx, ctx->up_prims.data(), static_cast<int>(ctx->up_prims.size()), accel, true,
                                      RM_SCENE_UPLOADED);
@@ -199,8 +237,12 @@ int ensure_scene(rm_ctx *ctx, int32_t preset_index, int32_t accel_in) {
     std::vector<rmh::PrimDesc> prims;  // torus / box presets: general primitive records
     if (rmh::preset_prims(preset, prims))
         return set_scene_general(ctx, prims.data(), static_cast<int>(prims.size()), accel, false, preset);
-    return fail(ctx, RM_E_UNSUPPORTED, "scene preset " + std::to_string(preset) +
-                                           " uses SDF operators or the Mandelbulb (not on the native path)");
+    std::vector<rmh::NodeDesc> nodes;  // operator / Mandelbulb presets: expression programs
+    std::vector<int> roots;
+    if (rmh::preset_nodes(preset, nodes, roots))
+        return set_scene_nodes(ctx, nodes.data(), static_cast<int>(nodes.size()), roots.data(),
+                               static_cast<int>(roots.size()), accel, false, preset);
+    return fail(ctx, RM_E_UNSUPPORTED, "scene preset " + std::to_string(preset) + " is not on the native path");
 }
 
 int ensure_scratch(rm_ctx *ctx, size_t bytes) {
@@ -248,8 +290,10 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
         p.light_d[k] = p.light[k];
     }
     p.n_prims = scene_n_prims(ctx);
-    p.general = ctx->host.general ? 1 : 0;
-    p.prims = ctx->dev.prims;
+    fill_scene_repr(ctx, p);
+    if (!std::isfinite(job->time)) return fail(ctx, RM_E_INVALID, "non-finite time");
+    ctx->time = job->time;  // raymarcher.ts:58-59 scene.updateTime(time)
+    p.time = job->time;
     p.accel = ctx->host.accel;
     p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
     p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());
@@ -392,7 +436,45 @@ int rm_scene_from_spheres(rm_ctx *ctx, const float *centers_xyz, const double *r
     ctx->up_centers.assign(centers_xyz, centers_xyz + 3 * static_cast<size_t>(n));
     ctx->up_radii.assign(radii, radii + n);
     ctx->up_general = false;
+    ctx->up_program = false;
     ctx->have_uploaded = true;
+    return RM_OK;
+}
+
+int rm_scene_from_nodes(rm_ctx *ctx, const rm_node *nodes, int32_t n_nodes, const int32_t *roots, int32_t n_roots,
+                        int32_t accel) {
+    if (!ctx) return RM_E_INVALID;
+    if (n_nodes < 0 || n_roots < 0 || (n_nodes > 0 && !nodes) || (n_roots > 0 && !roots))
+        return fail(ctx, RM_E_INVALID, "bad node list");
+    std::vector<rmh::NodeDesc> d(static_cast<size_t>(n_nodes));
+    for (int i = 0; i < n_nodes; ++i) {
+        d[i].type = nodes[i].type;
+        d[i].a = nodes[i].child_a;
+        d[i].b = nodes[i].child_b;
+        std::memcpy(d[i].m, nodes[i].world_to_local, sizeof d[i].m);
+        for (int k = 0; k < 6; ++k) d[i].params[k] = nodes[i].params[k];
+    }
+    std::vector<int> r(roots, roots + n_roots);
+    int rc = set_scene_nodes(ctx, d.data(), n_nodes, r.data(), n_roots, norm_accel(accel), true, RM_SCENE_UPLOADED);
+    if (rc) return rc;
+    ctx->up_nodes = std::move(d);
+    ctx->up_roots = std::move(r);
+    ctx->up_program = true;
+    ctx->up_general = false;
+    ctx->have_uploaded = true;
+    return RM_OK;
+}
+
+int rm_scale_transform(float *m, double x, double y, double z) {
+    if (!m || !std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) return RM_E_INVALID;
+    rmh::scale_transform(m, x, y, z);
+    return RM_OK;
+}
+
+int rm_scene_set_time(rm_ctx *ctx, double time) {
+    if (!ctx) return RM_E_INVALID;
+    if (!std::isfinite(time)) return fail(ctx, RM_E_INVALID, "non-finite time");
+    ctx->time = time;
     return RM_OK;
 }
 
@@ -409,6 +491,7 @@ int rm_scene_from_prims(rm_ctx *ctx, const rm_prim *prims, int32_t n, int32_t ac
     if (rc) return rc;
     ctx->up_prims = std::move(d);
     ctx->up_general = true;
+    ctx->up_program = false;
     ctx->have_uploaded = true;
     return RM_OK;
 }
@@ -645,8 +728,8 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     RmRenderParams p;
     std::memset(&p, 0, sizeof p);
     p.n_prims = scene_n_prims(ctx);
-    p.general = ctx->host.general ? 1 : 0;
-    p.prims = ctx->dev.prims;
+    fill_scene_repr(ctx, p);
+    p.time = ctx->time;
     p.accel = ctx->host.accel;
     p.bvh_nodes = static_cast<int32_t>(ctx->host.bvh.size());
     p.oct_nodes = static_cast<int32_t>(ctx->host.oct.size());
@@ -681,6 +764,29 @@ int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out) {
     RM_HIP(ctx, rm_launch_hypot(reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_out),
                                 ctx->stream));
     RM_HIP(ctx, hipMemcpyAsync(out, base + o_out, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RM_OK;
+}
+
+int rm_selftest_jsmath(rm_ctx *ctx, int32_t fn, const double *a, const double *b, int64_t n, double *out) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (n < 0 || fn < 0 || fn > 7 || (n > 0 && (!a || !out))) return fail(ctx, RM_E_INVALID, "bad buffers");
+    if (!n) return RM_OK;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t stride = align_up(8 * static_cast<size_t>(n), 256);
+    int rc = ensure_scratch(ctx, 3 * stride);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    RM_HIP(ctx, hipMemcpyAsync(base, a, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+    if (b) {
+        RM_HIP(ctx, hipMemcpyAsync(base + stride, b, 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        RM_HIP(ctx, hipMemsetAsync(base + stride, 0, 8 * static_cast<size_t>(n), ctx->stream));
+    }
+    RM_HIP(ctx, rm_launch_jsmath(fn, reinterpret_cast<const double *>(base), reinterpret_cast<const double *>(base + stride),
+                                 n, reinterpret_cast<double *>(base + 2 * stride), ctx->stream));
+    RM_HIP(ctx, hipMemcpyAsync(out, base + 2 * stride, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RM_OK;
 }

@@ -36,6 +36,8 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
                               uint32_t *count, hipStream_t stream);
 
 hipError_t rm_launch_hypot(const float *xyz, int64_t n, double *out, hipStream_t stream);
+// rm_jsmath.h on the device: fn 0 sin, 1 cos, 2 atan2, 3 asin, 4 log, 5 pow, 6 round, 7 atan
+hipError_t rm_launch_jsmath(int fn, const double *a, const double *b, int64_t n, double *out, hipStream_t stream);
 
 // compares the two device forms of Math.hypot on n generated triples; adds mismatches
 hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long long *d_mismatches, hipStream_t stream);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rm_device.h"
+#include "rm_program.h"
 #include "rm_kernels.h"
 
 namespace {
@@ -31,10 +32,18 @@ using namespace rmd;
 // GEN is a compile-time property of the kernel instantiation: a run-time `if (P.general)` in
 // front of the sphere loop changed the results of render_kernel<0, true> (lane-grouping
 // dependent wrong normals with hipcc 7.2), so the two representations never share a function body.
-template <bool GEN>
+// GEN: 0 RmSphere records, 1 RmPrim records, 2 expression programs (rm_program.h).
+template <int GEN>
 __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_t *ids, int n, const Vec3f &p,
                                            double closest) {
-    if (GEN) {
+    if (GEN == 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
+        for (int k = 0; k < n; ++k) {
+            const int obj = ids ? ids[k] : k;
+            closest = js_min_nan(program_sdf(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time), closest);
+        }
+        return closest;
+    }
+    if (GEN == 1) {
         for (int k = 0; k < n; ++k) closest = min_dist(prim_sdf_general(P.prims[ids ? ids[k] : k], p), closest);
         return closest;
     }
@@ -42,7 +51,7 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
 }
 
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
-template <bool GEN>
+template <int GEN>
 __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
     closest = list_min<GEN>(P, nullptr, P.n_prims, p, closest);
@@ -52,7 +61,7 @@ __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, ui
 
 // scene.ts:167-181 with BVH.getPrimitivesAt (bvh.ts:95-121): union of the primitives of
 // every leaf whose box contains p (a primitive lives in exactly one leaf), else all.
-template <bool GEN>
+template <int GEN>
 __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
@@ -94,7 +103,7 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
 }
 
 // scene.ts:148-166 given the node findNode returned
-template <bool GEN>
+template <int GEN>
 __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec3f &p, uint32_t &count) {
     if (node < 0) return all_prims_distance<GEN>(P, p, count);  // outside the cube: scene.ts:166,183-189
     const RmOctNode nd = P.oct[node];
@@ -108,7 +117,7 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
     return closest;
 }
 
-template <int ACCEL, bool GEN>
+template <int ACCEL, int GEN>
 __device__ __forceinline__ double scene_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     if (ACCEL == 2) return bvh_distance<GEN>(P, p, count);
     if (ACCEL == 1) return oct_node_distance<GEN>(P, oct_find(P, p), p, count);
@@ -155,7 +164,7 @@ __device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, double 
 
 // ------------------------------------------------------------------ the render kernel
 
-template <int ACCEL, bool GEN>
+template <int ACCEL, int GEN>
 __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, double depth, uint32_t &count,
                                    uint8_t nb[3]) {
     // raymarcher.ts:94-105
@@ -189,7 +198,7 @@ __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, doub
 }
 
 // SphereTracer.rayMarch (sphereTracer.ts:15-83)
-template <int ACCEL, bool GEN>
+template <int ACCEL, int GEN>
 __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
     double t = 0.0;
     Interval cur;
@@ -248,7 +257,7 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
 //   2 AdaptiveStep    adaptiveStep.ts:22-105    MAX_STEPS 200, step = clamp(0.8 d, 0.025, 0.5) or 0.01 near
 //   3 AdaptiveStepV2  adaptiveStepV2.ts:22-124  overshoot by overshootFactor, step back when spheres do not overlap
 //   4 AdaptiveStepV3  adaptiveStepV3.ts:22-137  as V2 plus the "bridging" third evaluation
-template <int ACCEL, bool GEN>
+template <int ACCEL, int GEN>
 __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
     const int alg = P.algorithm;
     const int max_steps = (alg == 1 || alg == 2) ? 200 : 100;
@@ -348,7 +357,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     return t;
 }
 
-template <int ACCEL, bool OTHER, bool GEN>
+template <int ACCEL, bool OTHER, int GEN>
 __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     // wave tile: tile_w x (64 / tile_w); four waves stacked vertically per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -489,7 +498,7 @@ __global__ void reduce_init_kernel(RmDiagDevice *acc) {
     acc->pad = 0;
 }
 
-template <int ACCEL, bool GEN>
+template <int ACCEL, int GEN>
 __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
                                                        uint32_t *count) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -565,10 +574,12 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
 #define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, 0, stream, p)
 #define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G); else if (p.accel == 1) RM_V1(1, O, G); else RM_V1(0, O, G); }
-    if (p.general) {
-        if (p.algorithm == 0) RM_V1A(false, true) else RM_V1A(true, true)
+    if (p.general == 2) {
+        if (p.algorithm == 0) RM_V1A(false, 2) else RM_V1A(true, 2)
+    } else if (p.general) {
+        if (p.algorithm == 0) RM_V1A(false, 1) else RM_V1A(true, 1)
     } else {
-        if (p.algorithm == 0) RM_V1A(false, false) else RM_V1A(true, false)
+        if (p.algorithm == 0) RM_V1A(false, 0) else RM_V1A(true, 0)
     }
 #undef RM_V1A
 #undef RM_V1
@@ -605,9 +616,33 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
 #define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, 0, stream, p, points, n, dist, count)
-    if (p.general) { if (p.accel == 2) RM_DK(2, true); else if (p.accel == 1) RM_DK(1, true); else RM_DK(0, true); }
-    else { if (p.accel == 2) RM_DK(2, false); else if (p.accel == 1) RM_DK(1, false); else RM_DK(0, false); }
+    if (p.general == 2) { if (p.accel == 2) RM_DK(2, 2); else if (p.accel == 1) RM_DK(1, 2); else RM_DK(0, 2); }
+    else if (p.general) { if (p.accel == 2) RM_DK(2, 1); else if (p.accel == 1) RM_DK(1, 1); else RM_DK(0, 1); }
+    else { if (p.accel == 2) RM_DK(2, 0); else if (p.accel == 1) RM_DK(1, 0); else RM_DK(0, 0); }
 #undef RM_DK
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void jsmath_kernel(int fn, const double *a, const double *b, int64_t n, double *out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    double r;
+    switch (fn) {
+        case 0: r = js_sin(x); break;
+        case 1: r = js_cos(x); break;
+        case 2: r = js_atan2(x, y); break;
+        case 3: r = js_asin(x); break;
+        case 4: r = js_log(x); break;
+        case 5: r = js_pow(x, y); break;
+        case 6: r = js_round(x); break;
+        default: r = js_atan(x); break;
+    }
+    out[i] = r;
+}
+
+hipError_t rm_launch_jsmath(int fn, const double *a, const double *b, int64_t n, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(jsmath_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, n, out);
     return hipGetLastError();
 }
 

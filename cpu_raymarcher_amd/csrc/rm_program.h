@@ -1,0 +1,132 @@
+// rm_program.h -- device interpreter for SDF expression programs (RmInstr, rm_types.h):
+// Primitive.sdf (primitive.ts:33-39) of Round / SmoothUnion / SmoothSubtraction / Twist / Repetition /
+// AnimatedTranslate (primitive_operations/*.ts) over Sphere / Box / Torus / Mandelbulb leaves.
+// Every wave executes the instruction stream of one object uniformly (the program counter and the
+// slot indices are wave-uniform); only the Mandelbulb's escape loop diverges per lane.
+#pragma once
+#include "rm_device.h"
+#include "rm_jsmath.h"
+
+namespace rmd {
+
+// Math.min / Math.max: NaN if either argument is NaN (the Mandelbulb can produce NaN at its pole)
+__device__ __forceinline__ double js_min_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
+__device__ __forceinline__ double js_max_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
+
+// vec3.transformMat4 into a Float32Array (w = w || 1.0)
+__device__ __forceinline__ void transform_mat4(const float *m, float fx, float fy, float fz, float &ox, float &oy, float &oz) {
+    const double x = fx, y = fy, z = fz;
+    double w = m[3] * x + m[7] * y + m[11] * z + m[15];
+    if (!(w != 0.0)) w = 1.0;
+    ox = to_f32((m[0] * x + m[4] * y + m[8] * z + m[12]) / w);
+    oy = to_f32((m[1] * x + m[5] * y + m[9] * z + m[13]) / w);
+    oz = to_f32((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
+}
+
+// mandelbulb.ts:37-78; z is a Float32Array: each component store rounds to binary32
+__device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, float lz, double time) {
+    const double power = prm[0], speed = prm[3];
+    const int iterations = static_cast<int>(prm[1]);
+    const bool animate = prm[2] != 0.0;
+    const float p0 = lx, p1 = lz, p2 = ly;  // p.xyz = p.xzy
+    float z0 = p0, z1 = p1, z2 = p2;
+    double dr = 1.0, r = 0.0;
+    for (int i = 0; i < iterations; ++i) {
+        r = hypot3(z0, z1, z2);
+        if (r > 2.0) break;
+        double theta = js_atan2(z1, z0);
+        double phi = js_asin(static_cast<double>(z2) / r);
+        if (animate) phi += time * speed;
+        dr = js_pow(r, power - 1.0) * dr * power + 1.0;
+        r = js_pow(r, power);
+        theta = theta * power;
+        phi = phi * power;
+        const double cphi = js_cos(phi);
+        z0 = to_f32(r * js_cos(theta) * cphi + static_cast<double>(p0));
+        z1 = to_f32(r * js_sin(theta) * cphi + static_cast<double>(p1));
+        z2 = to_f32(r * js_sin(phi) + static_cast<double>(p2));
+    }
+    return 0.5 * js_log(r) * r / dr;
+}
+
+// One scene object: returns Primitive.sdf(p) of the root node.
+__device__ inline double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time) {
+    float px[RM_PROG_MAX_SLOTS], py[RM_PROG_MAX_SLOTS], pz[RM_PROG_MAX_SLOTS];
+    double val[RM_PROG_MAX_VALS];
+    int sp = 0;
+    px[0] = p.x;
+    py[0] = p.y;
+    pz[0] = p.z;
+    for (int pc = first; pc < first + count; ++pc) {
+        const RmInstr &I = prog[pc];
+        const int op = I.op;
+        if (op >= 20) {  // POST
+            if (op == 20) {  // round.ts:24
+                val[sp - 1] = val[sp - 1] - I.p[0];
+            } else {
+                const double d1 = val[sp - 2], d2 = val[sp - 1];
+                const double k = I.p[0] * 4.0;
+                sp -= 1;
+                if (op == 21) {  // smoothUnion.ts:31-34
+                    const double h = js_max_nan(k - __builtin_fabs(d1 - d2), 0.0);
+                    val[sp - 1] = js_min_nan(d1, d2) - h * h * 0.25 / k;
+                } else {  // smoothSubstraction.ts:30-33
+                    const double h = js_max_nan(k - __builtin_fabs(d1 + d2), 0.0);
+                    val[sp - 1] = js_max_nan(d1, -d2) + h * h * 0.25 / k;
+                }
+            }
+            continue;
+        }
+        float lx, ly, lz;
+        transform_mat4(I.T, px[I.src], py[I.src], pz[I.src], lx, ly, lz);  // primitive.ts:34-35
+        if (op < 10) {  // leaves
+            double d;
+            if (op == 1) {  // box.ts:13-30
+                const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - I.p[0]);
+                const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - I.p[1]);
+                const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - I.p[2]);
+                const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
+                const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
+                d = hypot3(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
+            } else if (op == 2) {  // torus.ts:14-25
+                const double dx = lx, dy = ly, dz = lz;
+                const double qx = __builtin_sqrt(dx * dx + dz * dz) - I.p[0];
+                d = __builtin_sqrt(qx * qx + dy * dy) - I.p[1];
+            } else if (op == 3) {
+                d = mandelbulb_sdf(I.p, lx, ly, lz, time);
+            } else {  // sphere.ts:12-14
+                d = hypot3(lx, ly, lz) - I.p[0];
+            }
+            val[sp++] = d;
+            continue;
+        }
+        // PRE: the point the operands see
+        float wx, wy, wz;
+        if (op == 15) {  // animatedTranslate.ts:34-49: local - direction * (sin(time*speed)*amplitude)
+            const double offset = js_sin(time * I.p[4]) * I.p[3];
+            wx = to_f32(static_cast<double>(lx) - static_cast<double>(to_f32(I.p[0] * offset)));
+            wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(I.p[1] * offset)));
+            wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(I.p[2] * offset)));
+        } else {
+            transform_mat4(I.Tinv, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
+            if (op == 13) {  // twist.ts:21-33
+                const double a = I.p[0] * static_cast<double>(wy);
+                const double c = js_cos(a), s = js_sin(a);
+                const float tx = to_f32(c * static_cast<double>(wx) - s * static_cast<double>(wz));
+                const float tz = to_f32(s * static_cast<double>(wx) + c * static_cast<double>(wz));
+                wx = tx;
+                wz = tz;
+            } else if (op == 14) {  // repetition.ts:20-24
+                wx = to_f32(static_cast<double>(wx) - I.p[0] * js_round(static_cast<double>(wx) / I.p[0]));
+                wy = to_f32(static_cast<double>(wy) - I.p[1] * js_round(static_cast<double>(wy) / I.p[1]));
+                wz = to_f32(static_cast<double>(wz) - I.p[2] * js_round(static_cast<double>(wz) / I.p[2]));
+            }
+        }
+        px[I.dst] = wx;
+        py[I.dst] = wy;
+        pz[I.dst] = wz;
+    }
+    return val[0];
+}
+
+}  // namespace rmd

@@ -659,6 +659,294 @@ bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, 
     return build_accel(s, n, err);
 }
 
+// ---- expression forests ---------------------------------------------------------
+
+void scale_transform(float m[16], double x, double y, double z) {
+    for (int i = 0; i < 4; ++i) {
+        m[i] = to_f32(double(m[i]) * x);
+        m[4 + i] = to_f32(double(m[4 + i]) * y);
+        m[8 + i] = to_f32(double(m[8 + i]) * z);
+    }
+}
+
+namespace {
+
+struct Forest {
+    const NodeDesc *nodes;
+    int n;
+    std::vector<Mat4> T;  // Primitive.transform per node
+
+    // Primitive.transform: wrappers pass their operand's to super(), unions pass mat4.create()
+    void derive_transforms() {
+        T.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const NodeDesc &d = nodes[i];
+            if (d.type < 10) std::memcpy(T[i].m, d.m, sizeof T[i].m);
+            else if (d.type == 11 || d.type == 12) T[i] = Mat4::identity();
+            else T[i] = T[d.a];
+        }
+    }
+    // getWorldPosition: primitive.ts:20-30 and the overrides (smoothUnion.ts:52-60 midpoint, others: operand a)
+    void world_pos(int i, float out[3]) const {
+        const NodeDesc &d = nodes[i];
+        if (d.type == 11) {
+            float p1[3], p2[3];
+            world_pos(d.a, p1);
+            world_pos(d.b, p2);
+            for (int k = 0; k < 3; ++k) out[k] = to_f32((double(p1[k]) + double(p2[k])) / 2);
+            return;
+        }
+        if (d.type >= 10) return world_pos(d.a, out);
+        Mat4 l2w = Mat4::identity();
+        invert4(T[i].m, l2w.m);
+        for (int k = 0; k < 3; ++k) out[k] = l2w.m[12 + k];
+    }
+    // getLocalBoundingRadius of every class
+    double local_radius(int i) const {
+        const NodeDesc &d = nodes[i];
+        switch (d.type) {
+            case 0: return d.params[0];
+            case 1: return js_hypot3(to_f32(d.params[0]), to_f32(d.params[1]), to_f32(d.params[2]));
+            case 2: return d.params[0] + d.params[1];
+            case 3: return 2.5;                                   // mandelbulb.ts:80-83
+            case 10: return local_radius(d.a) + d.params[0];      // round.ts:27-30
+            case 13: return local_radius(d.a);                    // twist.ts:38-41
+            case 14: return std::numeric_limits<double>::infinity();  // repetition.ts:31-34
+            case 15: return local_radius(d.a) + d.params[3];      // animatedTranslate.ts:51-54
+            case 12: return local_radius(d.a);                    // smoothSubstraction.ts:36-39
+            default: {                                            // smoothUnion.ts:37-49
+                float p1[3], p2[3];
+                world_pos(d.a, p1);
+                world_pos(d.b, p2);
+                const double dist = js_hypot3(double(p2[0]) - double(p1[0]), double(p2[1]) - double(p1[1]),
+                                              double(p2[2]) - double(p1[2]));
+                return js_max2(local_radius(d.a), local_radius(d.b)) + dist * 0.5;
+            }
+        }
+    }
+    // post-order instruction stream of the subtree rooted at i, reading its point from slot `slot`
+    bool compile(int i, int slot, int &depth_vals, std::vector<RmInstr> &out, std::string &err) const {
+        if (slot + 1 >= RM_PROG_MAX_SLOTS) {
+            err = "expression tree deeper than RM_PROG_MAX_SLOTS";
+            return false;
+        }
+        const NodeDesc &d = nodes[i];
+        RmInstr ins;
+        std::memset(&ins, 0, sizeof ins);
+        std::memcpy(ins.T, T[i].m, sizeof ins.T);
+        Mat4 inv = Mat4::identity();
+        invert4(T[i].m, inv.m);  // stays identity when singular, like mat4.invert's untouched `out`
+        std::memcpy(ins.Tinv, inv.m, sizeof ins.Tinv);
+        for (int k = 0; k < 6; ++k) ins.p[k] = d.params[k];
+        if (d.type == 1 || d.type == 14 || d.type == 15)  // vec3 members are Float32Arrays
+            for (int k = 0; k < 3; ++k) ins.p[k] = to_f32(d.params[k]);
+        ins.op = d.type;
+        ins.src = slot;
+        ins.dst = slot + 1;
+        if (d.type < 10) {
+            out.push_back(ins);
+            if (++depth_vals > RM_PROG_MAX_VALS) {
+                err = "expression needs more than RM_PROG_MAX_VALS pending values";
+                return false;
+            }
+            return true;
+        }
+        out.push_back(ins);  // PRE
+        if (!compile(d.a, slot + 1, depth_vals, out, err)) return false;
+        const bool binary = d.type == 11 || d.type == 12;
+        if (binary && !compile(d.b, slot + 1, depth_vals, out, err)) return false;
+        if (binary || d.type == 10) {
+            ins.op = d.type + 10;  // POST
+            out.push_back(ins);
+            if (binary) --depth_vals;
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+bool preset_nodes(int index, std::vector<NodeDesc> &nodes, std::vector<int> &roots) {
+    nodes.clear();
+    roots.clear();
+    index = std::max(0, std::min(index, kPresetCount - 1));
+    const double PI = 3.141592653589793;
+    auto leaf = [&](int type, double x, double y, double z, const float *rot, double p0, double p1, double p2) {
+        NodeDesc d;
+        d.type = type;
+        make_transform(x, y, z, rot, d.m);
+        for (double &v : d.params) v = 0;
+        d.params[0] = p0;
+        d.params[1] = p1;
+        d.params[2] = p2;
+        nodes.push_back(d);
+        return static_cast<int>(nodes.size()) - 1;
+    };
+    auto sphere = [&](double x, double y, double z, double r) { return leaf(0, x, y, z, nullptr, r, 0, 0); };
+    auto box = [&](double x, double y, double z, double hx, double hy, double hz, const float *rot = nullptr) {
+        return leaf(1, x, y, z, rot, hx, hy, hz);
+    };
+    auto torus = [&](double x, double y, double z, double radius, const float *rot) {
+        return leaf(2, x, y, z, rot, radius, radius / 4, 0);  // sceneManager.ts:47-49
+    };
+    auto op = [&](int type, int a, int b, double p0) {
+        NodeDesc d;
+        d.type = type;
+        d.a = a;
+        d.b = b;
+        std::memset(d.m, 0, sizeof d.m);
+        for (double &v : d.params) v = 0;
+        d.params[0] = p0;
+        nodes.push_back(d);
+        return static_cast<int>(nodes.size()) - 1;
+    };
+    switch (index) {
+        case 6:  // "Rounded Box"
+            roots.push_back(op(10, box(0, 0, 0, 0.4, 0.4, 0.4), -1, 0.3));
+            return true;
+        case 10:  // "Smooth Union"
+            roots.push_back(op(11, sphere(0, 0, 0, 0.5), box(0, 0.5, 0, 1, 0.2, 1), 0.2));
+            return true;
+        case 11: {  // "Smooth Subtraction"
+            const float rot[3] = {0.0f, to_f32(PI / 4), 0.0f};
+            const int a = op(10, box(0, 0, 0, 1, 1, 1, rot), -1, 0.1);
+            roots.push_back(op(12, a, sphere(0, 0, 0, 0.9), 0.2));
+            return true;
+        }
+        case 12: {  // "Smooth Union [A]": AnimatedTranslate(sphere, (1,0,0), 3.0, 0.005)
+            const int a = op(15, sphere(0, 0, 0, 1), -1, 0);
+            const float dir[3] = {1.0f, 0.0f, 0.0f};
+            float nd[3];
+            double len = double(dir[0]) * dir[0] + double(dir[1]) * dir[1] + double(dir[2]) * dir[2];
+            if (len > 0) len = 1 / std::sqrt(len);  // vec3.normalize (animatedTranslate.ts:22-23)
+            for (int k = 0; k < 3; ++k) nd[k] = to_f32(double(dir[k]) * len);
+            nodes[a].params[0] = nd[0];
+            nodes[a].params[1] = nd[1];
+            nodes[a].params[2] = nd[2];
+            nodes[a].params[3] = 3.0;
+            nodes[a].params[4] = 0.005;
+            roots.push_back(op(11, a, sphere(0, 0, 0, 1), 0.2));
+            return true;
+        }
+        case 13: {  // "Mandelbulb [A]": createMandelbulb(0,0,0, 8, 80, true, -0.0001)
+            const int m = leaf(3, 0, 0, 0, nullptr, 8, 80, 1);
+            nodes[m].params[3] = -0.0001;
+            scale_transform(nodes[m].m, 0.5, 0.5, 0.5);
+            roots.push_back(m);
+            return true;
+        }
+        case 14: {  // "Twisted Torus"
+            const float rot[3] = {to_f32(-PI / 2), 0.0f, 0.0f};
+            roots.push_back(op(13, torus(0, 0, 0, 1.3, rot), -1, 3));
+            return true;
+        }
+        case 15: {  // "Infinite Spheres"
+            const int r = op(14, sphere(0, 0, 0, 0.3), -1, 1.5);
+            nodes[r].params[1] = 1.5;
+            nodes[r].params[2] = 1.5;
+            roots.push_back(r);
+            return true;
+        }
+        case 16:  // "Screw"
+            roots.push_back(op(10, op(13, box(0, 0, 0, 0.4, 1.5, 0.4), -1, 4.0), -1, 0.1));
+            return true;
+        case 17: {  // "Chicken"
+            static const double b[10][6] = {
+                {0, 0, 0, 0.6, 0.6, 0.8},      {0, -0.2, 0, 0.8, 0.4, 0.6},   {0, -0.8, 0.8, 0.4, 0.6, 0.3},
+                {0, -0.8, 1.2, 0.4, 0.2, 0.2}, {0, -0.4, 1.0, 0.2, 0.2, 0.2}, {0.3, 1, 0, 0.1, 0.6, 0.01},
+                {-0.3, 1, 0, 0.1, 0.6, 0.01},  {0, 1.6, 0.2, 0.6, 0.01, 0.2}, {0.3, 1.6, 0.5, 0.1, 0.01, 0.1},
+                {-0.3, 1.6, 0.5, 0.1, 0.01, 0.1}};
+            int acc = box(b[0][0], b[0][1], b[0][2], b[0][3], b[0][4], b[0][5]);
+            for (int i = 1; i < 10; ++i) acc = op(11, acc, box(b[i][0], b[i][1], b[i][2], b[i][3], b[i][4], b[i][5]), 0.0001);
+            roots.push_back(acc);
+            return true;
+        }
+        case 18: {  // "67"
+            const float r5[3] = {0.0f, 0.0f, to_f32(PI / 5)}, r7[3] = {0.0f, 0.0f, to_f32(PI / 7)};
+            const float r2[3] = {0.0f, 0.0f, to_f32(PI / 2)}, rt[3] = {to_f32(-PI / 2), 0.0f, 0.0f};
+            const int six_a = op(10, box(-1.25, -0.8, 0, 0.05, 0.7, 0.05, r5), -1, 0.20);
+            const int six_b = op(10, torus(-1.25, 0.5, 0, 0.8, rt), -1, 0.05);
+            roots.push_back(op(11, six_a, six_b, 0.0001));
+            const int sev_a = op(10, box(1.35, 0, 0, 0.05, 1.5, 0.05, r7), -1, 0.20);
+            const int sev_b = op(10, box(1.25, -1.4, 0, 0.05, 0.8, 0.05, r2), -1, 0.20);
+            roots.push_back(op(11, sev_a, sev_b, 0.0001));
+            return true;
+        }
+        default:
+            return false;
+    }
+}
+
+bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const int *roots, int n_roots, int accel,
+                       std::string &err) {
+    if (n_nodes < 0 || n_roots < 0 || (n_nodes > 0 && !nodes) || (n_roots > 0 && !roots)) {
+        err = "bad node list";
+        return false;
+    }
+    for (int i = 0; i < n_nodes; ++i) {
+        const NodeDesc &d = nodes[i];
+        const bool leaf = d.type >= 0 && d.type <= 3, unary = d.type == 10 || (d.type >= 13 && d.type <= 15);
+        const bool binary = d.type == 11 || d.type == 12;
+        if (!leaf && !unary && !binary) {
+            err = "unknown node type";
+            return false;
+        }
+        if (!leaf && (d.a < 0 || d.a >= i || (binary && (d.b < 0 || d.b >= i)))) {
+            err = "operand index must name an earlier node";
+            return false;
+        }
+        if (leaf)
+            for (int k = 0; k < 16; ++k)
+                if (!std::isfinite(d.m[k])) {
+                    err = "non-finite transform";
+                    return false;
+                }
+        for (int k = 0; k < 6; ++k)
+            if (!std::isfinite(d.params[k])) {
+                err = "non-finite node parameter";
+                return false;
+            }
+    }
+    for (int r = 0; r < n_roots; ++r)
+        if (roots[r] < 0 || roots[r] >= n_nodes) {
+            err = "root index out of range";
+            return false;
+        }
+    s = HostScene();
+    s.accel = (accel == 1 || accel == 2) ? accel : 0;
+    s.general = true;  // not the compact sphere path
+    s.program = true;
+    Forest f{nodes, n_nodes, {}};
+    f.derive_transforms();
+    s.prim_lo.resize(3 * size_t(n_roots));
+    s.prim_hi.resize(3 * size_t(n_roots));
+    s.world_pos.resize(3 * size_t(n_roots));
+    for (int r = 0; r < n_roots; ++r) {
+        const int root = roots[r];
+        const int first = static_cast<int>(s.prog.size());
+        int vals = 0;
+        if (!f.compile(root, 0, vals, s.prog, err)) return false;
+        s.obj_ranges.push_back(first);
+        s.obj_ranges.push_back(static_cast<int>(s.prog.size()) - first);
+        // BoundingBox.fromPrimitive (boundingBox.ts:133-154) with the overridden getters
+        float wp[3];
+        f.world_pos(root, wp);
+        const double local_radius = f.local_radius(root);
+        Mat4 l2w = Mat4::identity();
+        const bool ok = invert4(f.T[root].m, l2w.m);
+        const float *m = ok ? l2w.m : f.T[root].m;
+        const double scale = js_max2(js_max2(js_hypot3(m[0], m[1], m[2]), js_hypot3(m[4], m[5], m[6])),
+                                     js_hypot3(m[8], m[9], m[10]));
+        const double pad = local_radius * scale * 1.5;
+        for (int k = 0; k < 3; ++k) {
+            s.world_pos[3 * r + k] = wp[k];
+            s.prim_lo[3 * r + k] = to_f32(double(wp[k]) - pad);
+            s.prim_hi[3 * r + k] = to_f32(double(wp[k]) + pad);
+        }
+    }
+    return build_accel(s, n_roots, err);
+}
+
 void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]) {
     const double half_pi = 3.141592653589793 / 2;
     const double p = js_min2(js_max2(pitch, -half_pi), half_pi);  // camera.ts:59

@@ -19,10 +19,23 @@ struct PrimDesc {
     double params[3];    // sphere: r; box: halfSize; torus: major, minor
 };
 
+// one node of an SDF expression forest as the ABI hands it over (include/rm_raymarch.h: rm_node).
+// Operands must precede the node that uses them (a, b < own index).
+struct NodeDesc {
+    int type = 0;        // 0 sphere, 1 box, 2 torus, 3 mandelbulb, 10 round, 11 smooth union, 12 smooth subtraction,
+                         // 13 twist, 14 repetition, 15 animated translate
+    int a = -1, b = -1;  // operand node indices
+    float m[16];         // leaves: world -> local.  Operators derive theirs (wrappers: the operand's; unions: identity)
+    double params[6];    // see RmInstr::p
+};
+
 struct HostScene {
     int accel = 0;
     int preset = 0;
     bool general = false;         // RmPrim records instead of RmSphere
+    bool program = false;         // expression programs (RmInstr) instead of either
+    std::vector<RmInstr> prog;
+    std::vector<int32_t> obj_ranges;  // (first, count) per scene object
     std::vector<RmPrim> prims;
     std::vector<float> world_pos; // Primitive.getWorldPosition() per primitive (BVH sort key)
     std::vector<RmSphere> spheres;
@@ -68,6 +81,16 @@ bool preset_prims(int index, std::vector<PrimDesc> &out);
 
 // general scenes (any mix of spheres, boxes, tori, rotated or not)
 bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, std::string &err);
+
+// presets 6 and 10-18 (SDF operators, Mandelbulb: sceneManager.ts:178-356) as expression forests
+bool preset_nodes(int index, std::vector<NodeDesc> &nodes, std::vector<int> &roots);
+
+// scenes whose objects are expression trees (any preset can be expressed this way)
+bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const int *roots, int n_roots, int accel,
+                       std::string &err);
+
+// gl-matrix mat4.scale(m, m, [x, y, z]) in place (sceneManager.ts:63: the Mandelbulb's world->local is post-scaled)
+void scale_transform(float m[16], double x, double y, double z);
 
 // camera.ts:58-69,81-88 + raymarcher.ts:62-67
 void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]);

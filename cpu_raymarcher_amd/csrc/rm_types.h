@@ -55,6 +55,25 @@ struct RmPrim {
     double a, b;    // sphere: radius, -; torus: majorRadius, minorRadius
 };
 
+// Expression trees (primitive_operations/*.ts, mandelbulb.ts) are compiled by the host
+// into a linear program per scene object, evaluated by every lane with a small position-slot file
+// and a value stack (rm_program.h).  An operator node becomes a PRE instruction (computes the point
+// its operands are evaluated at, into slot `dst`), the operands' instructions, and -- for Round and
+// the smooth unions -- a POST instruction that combines the values on the stack.
+//   op: 0 sphere, 1 box, 2 torus, 3 mandelbulb (leaves: push localSdf(T * pos[src]))
+//       10 round, 11 smooth union, 12 smooth subtraction, 13 twist, 14 repetition, 15 animated translate (PRE)
+//       20 round, 21 smooth union, 22 smooth subtraction (POST)
+//   p:  sphere r | box halfSize | torus major, minor | mandelbulb power, iterations, enableAnimation, speed |
+//       round radius | unions smoothness | twist amount | repetition spacing | animated: direction, amplitude, speed
+struct RmInstr {
+    float T[16];     // world -> local of the node (Primitive.transform)
+    float Tinv[16];  // mat4.invert(T) as the operators recompute it per call (identity when singular)
+    double p[6];
+    int32_t op, src, dst, pad;
+};
+#define RM_PROG_MAX_SLOTS 16
+#define RM_PROG_MAX_VALS 16
+
 #define RM_BVH_LEAF_MAX 255
 #define RM_MAX_STEPS 100
 #define RM_MAX_DIST 10.0
@@ -103,9 +122,12 @@ struct RmRenderParams {
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;
     int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)
-    int32_t general;     // 1: primitives are RmPrim records (`prims`), not RmSphere
+    int32_t general;     // 0: RmSphere records; 1: RmPrim records (`prims`); 2: expression programs (`prog`)
     int32_t reserved3;
     const RmPrim *prims;
+    const RmInstr *prog;         // general == 2: instructions of every scene object, concatenated
+    const int32_t *obj_ranges;   // general == 2: (first, count) into prog per scene object
+    double time;                 // Scene.updateTime(time) (raymarcher.ts:58-59): animated primitives
     double overshoot;    // AdaptiveStepV2/V3 overshootFactor (default 1.2)
     double step_size;    // FixedStep stepSize (default 0.1)
     const RmSphere *spheres;

@@ -79,6 +79,15 @@ class Scene:
         self.ctx.scene_from_prims(prims, self.accel_enum)
         self._uploaded = True
 
+    def loadNodes(self, nodes, roots):
+        """Build-defined: an SDF expression forest (operators of util/primitive_operations/ over
+        sphere / box / torus / mandelbulb leaves); see Context.scene_from_nodes."""
+        self.ctx.scene_from_nodes(nodes, roots, self.accel_enum)
+        self._uploaded = True
+
+    def updateTime(self, time):  # scene.ts:135-140
+        self.ctx.scene_set_time(time)
+
     @property
     def preset_for_job(self):
         return N.RM_SCENE_UPLOADED if self._uploaded else self.currentPresetIndex

@@ -132,9 +132,9 @@ RM_API int rm_preset_count(void);                   /* sceneManager.ts:363-365 *
 
 /* Replaces `new Scene(accel); scene.loadPreset(index)` (scene.ts:24-59,
  * raymarchWorker.ts:37-38): builds the primitive list, the BVH (bvh.ts:29-92) or Octree
- * (octree.ts:36-191), flattens it and uploads it.  Presets 0..4 (spheres) and 5, 7, 8, 9
- * (torus, boxes) are native; presets with SDF operators or the Mandelbulb return
- * RM_E_UNSUPPORTED. */
+ * (octree.ts:36-191), flattens it and uploads it.  All 19 presets are native: 0..4 (spheres),
+ * 5, 7, 8, 9 (torus, boxes), 6 and 10..18 (SDF operators, Mandelbulb; index clamps like
+ * sceneManager.ts:359-361). */
 RM_API int rm_scene_from_preset(rm_ctx *ctx, int32_t preset_index, int32_t accel);
 
 /* Build-defined scene entry: n spheres as SceneManager.createSphere(x, y, z, r) without
@@ -162,6 +162,41 @@ RM_API int rm_scene_from_prims(rm_ctx *ctx, const rm_prim *prims, int32_t n, int
  * matrix of a primitive; rotation_xyz may be NULL (no rotation argument) or three Euler
  * angles stored as binary32 like a gl-matrix vec3. */
 RM_API int rm_make_transform(double x, double y, double z, const float *rotation_xyz, float *world_to_local16);
+
+/* SDF expression forests: the operator classes of util/primitive_operations/
+ * (round.ts, smoothUnion.ts, smoothSubstraction.ts, twist.ts, repetition.ts, animatedTranslate.ts)
+ * over Sphere / Box / Torus / Mandelbulb (primitives/mandelbulb.ts) leaves.  All 19 presets of
+ * sceneManager.ts:102-357 are served natively through rm_scene_from_preset / rm_job; this entry
+ * takes an arbitrary forest.  Operands must precede the node that uses them. */
+typedef enum rm_node_type {
+    RM_NODE_SPHERE = 0, RM_NODE_BOX = 1, RM_NODE_TORUS = 2, RM_NODE_MANDELBULB = 3,
+    RM_NODE_ROUND = 10, RM_NODE_SMOOTH_UNION = 11, RM_NODE_SMOOTH_SUBTRACTION = 12,
+    RM_NODE_TWIST = 13, RM_NODE_REPETITION = 14, RM_NODE_ANIMATED_TRANSLATE = 15
+} rm_node_type;
+typedef struct rm_node {
+    int32_t type;               /* rm_node_type */
+    int32_t child_a, child_b;   /* operand node indices (< own index); -1 when unused */
+    int32_t reserved;
+    float   world_to_local[16]; /* leaves: Primitive.transform.  Operators derive theirs as their
+                                 * constructors do (wrappers: the operand's; unions: identity) */
+    double  params[6];          /* sphere: radius | box: halfSize | torus: major, minor |
+                                 * mandelbulb: power, iterations, enableAnimation, animationSpeed |
+                                 * round: radius | unions: smoothness | twist: twistAmount |
+                                 * repetition: spacing x,y,z | animated translate: the NORMALISED
+                                 * direction x,y,z (animatedTranslate.ts:22-23), amplitude, speed */
+} rm_node;
+
+/* roots[] lists the nodes that are Scene.objects, in order; selected in jobs by RM_SCENE_UPLOADED.
+ * RM_E_UNSUPPORTED when a tree is deeper than the device interpreter's 15 nested operators. */
+RM_API int rm_scene_from_nodes(rm_ctx *ctx, const rm_node *nodes, int32_t n_nodes, const int32_t *roots,
+                               int32_t n_roots, int32_t accel);
+
+/* gl-matrix mat4.scale(m, m, [x, y, z]) in place: SceneManager.createMandelbulb post-scales the
+ * world->local matrix by 0.5 (sceneManager.ts:63). */
+RM_API int rm_scale_transform(float *world_to_local16, double x, double y, double z);
+
+/* Scene.updateTime(time) (scene.ts:135-140) for rm_scene_distance; renders take rm_job.time. */
+RM_API int rm_scene_set_time(rm_ctx *ctx, double time);
 
 RM_API int rm_scene_get_info(const rm_ctx *ctx, rm_scene_info *out);
 
@@ -233,6 +268,10 @@ RM_API int rm_partition_rows(int32_t height, int32_t n_workers, int32_t i, int32
 
 /* V8 Math.hypot of n float triples evaluated by the device code path used in Sphere.sdf */
 RM_API int rm_selftest_hypot(rm_ctx *ctx, const float *xyz, int64_t n, double *out);
+
+/* JS Math.* as the device computes them (csrc/rm_jsmath.h, fdlibm restated like V8's ieee754.cc):
+ * fn 0 sin, 1 cos, 2 atan2(a, b), 3 asin, 4 log, 5 pow(a, b), 6 round, 7 atan; b may be NULL. */
+RM_API int rm_selftest_jsmath(rm_ctx *ctx, int32_t fn, const double *a, const double *b, int64_t n, double *out);
 
 /* Device check of the shared-reciprocal division used by the v2 kernel's sphere SDF: evaluates
  * Math.hypot with the compiler's IEEE divisions and with the shared reciprocal on n generated

@@ -8,7 +8,7 @@ const R = require('./host/raymarcher.js');
 const cfg = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const out = process.argv[3];
 const H = cfg.height, W = cfg.width;
-const job = { width: W, height: H, time: 0, yStart: cfg.yStart === undefined ? 0 : cfg.yStart,
+const job = { width: W, height: H, time: cfg.time || 0, yStart: cfg.yStart === undefined ? 0 : cfg.yStart,
   yEnd: cfg.yEnd === undefined ? H : cfg.yEnd, camera: { pitch: cfg.pitch || 0, yaw: cfg.yaw || 0 },
   algorithm: cfg.algorithm || 'sphere-tracer', scenePresetIndex: cfg.preset, accelerationStructure: cfg.accel,
   overshootFactor: cfg.overshootFactor, stepSize: cfg.stepSize };

@@ -67,6 +67,24 @@ CASES = {
     "N3_mixed40_360p_bvh": dict(mixed=40, accel="BVH", width=640, height=360, shader="phong", pitch=0.2, yaw=0.3, js="full"),
     "N3_mixed40_360p_octree": dict(mixed=40, accel="Octree", width=640, height=360, shader="normal", pitch=-0.6,
                                    yaw=2.0, js="full"),
+    # SDF operators and the Mandelbulb; `time` feeds the animated primitives
+    "N4_rounded_box_360p_bvh": dict(preset=6, accel="BVH", width=640, height=360, shader="phong", pitch=0.4, yaw=0.6, js="full"),
+    "N4_smooth_union_360p_none": dict(preset=10, accel="None", width=640, height=360, shader="normal", pitch=0.5, yaw=-0.4,
+                                      js="full"),
+    "N4_smooth_sub_360p_octree_v3": dict(preset=11, accel="Octree", width=640, height=360, shader="sdf-heatmap",
+                                         algorithm="adaptive-step-v3", pitch=0.3, yaw=0.8, js="full"),
+    "N4_smooth_union_anim_360p_none_t2500": dict(preset=12, accel="None", width=640, height=360, shader="phong", time=2500.0,
+                                                 js="full"),
+    "N4_mandelbulb_270p_bvh_t1000": dict(preset=13, accel="BVH", width=480, height=270, shader="iteration-heatmap",
+                                         time=1000.0, pitch=0.2, yaw=0.5, js="full"),
+    "N4_twisted_torus_360p_bvh": dict(preset=14, accel="BVH", width=640, height=360, shader="phong", pitch=0.6, yaw=1.2,
+                                      js="full"),
+    "N4_infinite_spheres_360p_octree": dict(preset=15, accel="Octree", width=640, height=360, shader="iteration-heatmap",
+                                            pitch=0.1, yaw=0.2, js="full"),
+    "N4_screw_360p_none_adaptive": dict(preset=16, accel="None", width=640, height=360, shader="normal",
+                                        algorithm="adaptive-step", pitch=-0.2, yaw=0.9, js="full"),
+    "N4_chicken_360p_bvh": dict(preset=17, accel="BVH", width=640, height=360, shader="phong", pitch=0.3, yaw=2.4, js="full"),
+    "N4_67_360p_octree": dict(preset=18, accel="Octree", width=640, height=360, shader="sdf-heatmap", js="full"),
     "M6_fixed_default_270p_none": dict(preset=2, accel="None", width=480, height=270, shader="sdf-heatmap",
                                        algorithm="fixed-step", js="full"),
 }
@@ -93,7 +111,7 @@ def c_render(cfg, y0=None, y1=None, width=None, height=None):
     with ThreadPoolExecutor(THREADS) as ex:
         parts = list(ex.map(lambda b: sc.render(W, H, b[0], b[1], algorithm=cfg.get("algorithm", "sphere-tracer"),
                                                 overshoot_factor=cfg.get("overshootFactor"),
-                                                step_size=cfg.get("stepSize")), bands))
+                                                step_size=cfg.get("stepSize"), time=cfg.get("time", 0.0)), bands))
     d, n, s, i = (np.concatenate([p[k] for p in parts]) for k in range(4))
     rgba = O.shade(cfg["shader"], d, n, s, i, W, y1 - y0)
     return d, n, s, i, rgba
@@ -115,7 +133,7 @@ def js_render(cfg, y0=None, y1=None, width=None, height=None):
             j["prims"] = O.synthetic_mixed_prims(cfg["mixed"])
         else:
             j["preset"] = cfg["preset"]
-        for k in ("algorithm", "overshootFactor", "stepSize"):
+        for k in ("algorithm", "overshootFactor", "stepSize", "time"):
             if k in cfg:
                 j[k] = cfg[k]
         with open(os.path.join(td, "cfg.json"), "w") as f:

@@ -15,9 +15,11 @@ NAMES = ("depth", "normal", "sdf", "iters")
 
 
 def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
-               overshoot=None, step=None, prims=None):
+               overshoot=None, step=None, prims=None, time=0.0, nodes=None):
     sc = rm.Scene(accel, ctx=ctx)
-    if prims is not None:  # (type, world_to_local, params) triples, e.g. OracleScene.prims()
+    if nodes is not None:  # (node tuples, roots) as OracleScene.nodes() returns them
+        sc.loadNodes(*nodes)
+    elif prims is not None:  # (type, world_to_local, params) triples, e.g. OracleScene.prims()
         sc.loadPrims(prims)
     elif spheres is not None:
         sc.loadSpheres(spheres[:, :3], spheres[:, 3])
@@ -27,16 +29,16 @@ def gpu_render(rm, ctx, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=
     y0, y1 = rows if rows else (0, H)
     n = W * max(0, y1 - y0)
     bufs = (np.zeros(n, np.uint8), np.zeros(3 * n, np.uint8), np.zeros(n, np.uint16), np.zeros(n, np.uint16))
-    rm.createRaymarcher(algorithm, overshoot, step).runRaymarcher(sc, *bufs, W, H, 0.0, y0, y1)
+    rm.createRaymarcher(algorithm, overshoot, step).runRaymarcher(sc, *bufs, W, H, time, y0, y1)
     return bufs
 
 
 def cpu_render(oracle, preset, accel, W, H, ang=(0.0, 0.0), rows=None, spheres=None, algorithm="sphere-tracer",
-               overshoot=None, step=None, prims=None):
+               overshoot=None, step=None, prims=None, time=0.0):
     sc = oracle.OracleScene(preset=preset, accel=accel, spheres=spheres, prims=prims)
     sc.set_angles(*ang)
     y0, y1 = rows if rows else (0, H)
-    return sc.render(W, H, y0, y1, algorithm=algorithm, overshoot_factor=overshoot, step_size=step)
+    return sc.render(W, H, y0, y1, algorithm=algorithm, overshoot_factor=overshoot, step_size=step, time=time)
 
 
 def assert_same(got, want, what):
@@ -315,7 +317,8 @@ def test_golden_fixtures_at_baseline_sizes(rm, gpu_ctx, oracle, golden, golden_c
             prims = oracle.OracleScene(accel="None", prims=oracle.synthetic_mixed_prims(cfg["mixed"])).prims()
         got = gpu_render(rm, gpu_ctx, cfg.get("preset"), cfg["accel"], W, H, (cfg.get("pitch", 0.0), cfg.get("yaw", 0.0)),
                          spheres=spheres, algorithm=cfg.get("algorithm", "sphere-tracer"),
-                         overshoot=cfg.get("overshootFactor"), step=cfg.get("stepSize"), prims=prims)
+                         overshoot=cfg.get("overshootFactor"), step=cfg.get("stepSize"), prims=prims,
+                         time=cfg.get("time", 0.0))
         rgba = np.zeros(4 * W * H, np.uint8)
         rm.createShadingModelFromValue(cfg["shader"], gpu_ctx).shade(rgba, *got, W, H)
         c = g["crop"]
@@ -399,3 +402,105 @@ def test_mixed_rotated_primitives_and_make_transform(rm, gpu_ctx, oracle):
     ob = oracle.OracleScene(accel="BVH", prims=desc)
     for k in range(0, 500, 5):
         assert (d[k], c[k]) == ob.distance(pts[k])
+
+
+# ---- SDF operators and the Mandelbulb ------------------------------------------
+
+def _jsmath_cases(rng, n):
+    trig = np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-8e5, 8e5, n // 4), rng.normal(0, 1e-3, n // 8),
+                           (np.arange(n // 8) - n // 16) * np.pi / 2 * (1 + rng.normal(0, 1e-9, n // 8))])
+    y = rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 5, n)
+    x = rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 5, n)
+    unit = np.concatenate([rng.uniform(-1.01, 1.01, n - 1000), 1 - 10.0 ** rng.uniform(-16, 0, 1000)])
+    pos = np.concatenate([rng.uniform(-0.1, 4, n // 2), 10.0 ** rng.uniform(-320, 300, n // 2)])
+    rnd = np.concatenate([rng.uniform(-100, 100, n - 9), [0.5, -0.5, 1.5, -1.5, 2.5, -2.5, -0.0, 0.49999999999999994, -0.2]])
+    pw_x = np.concatenate([rng.uniform(0, 2.5, n // 2), 10.0 ** rng.uniform(-20, 20, n // 4), rng.uniform(-5, 5, n // 4)])
+    pw_y = np.concatenate([rng.choice([7.0, 8.0, 2.0, 0.5, 3.0, -1.0], n // 4), rng.uniform(-10, 10, n // 4),
+                           rng.uniform(-30, 30, n // 4), rng.integers(-9, 9, n // 4).astype(float)])
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 5e-324, 1e308, 2.0 ** -1022])
+    sa, sb = [v.ravel() for v in np.meshgrid(special, special)]
+    return {0: (np.r_[trig, special], None), 1: (np.r_[trig, special], None), 2: (np.r_[y, sa], np.r_[x, sb]),
+            3: (np.r_[unit, special], None), 4: (np.r_[pos, special], None), 5: (np.r_[pw_x, sa], np.r_[pw_y, sb]),
+            6: (np.r_[rnd, special], None), 7: (np.r_[y, special], None)}
+
+
+def test_device_jsmath_is_bit_identical_to_the_oracle(gpu_ctx, oracle):
+    """csrc/rm_jsmath.h (device) == oracle/ro_jsmath.h (which is pinned against node's Math.*)."""
+    import ctypes
+    L = oracle.lib()
+    L.ro_jsmath_eval.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_long]
+    for fn, (a, b) in _jsmath_cases(np.random.default_rng(21), 400000).items():
+        a = np.ascontiguousarray(a)
+        bb = np.zeros_like(a) if b is None else np.ascontiguousarray(b)
+        want = np.zeros_like(a)
+        L.ro_jsmath_eval(fn, a.ctypes.data, bb.ctypes.data, want.ctypes.data, len(a))
+        got = gpu_ctx.selftest_jsmath(fn, a, b)
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (fn, int((~same).sum()), a[~same][:3], got[~same][:3], want[~same][:3])
+
+
+@pytest.mark.parametrize("preset", [6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+def test_operator_and_mandelbulb_presets(rm, gpu_ctx, oracle, preset):
+    W, H = (120, 80) if preset == 13 else (200, 120)
+    for accel in ("None", "BVH", "Octree"):
+        for alg, tm, ang in (("sphere-tracer", 0.0, (0.0, 0.0)), ("adaptive-step-v3", 1234.5, (0.3, 0.8)),
+                             ("fixed-step", 77.0, (-0.4, 2.0))):
+            if preset == 13 and alg == "fixed-step" and accel != "None":
+                continue  # the Mandelbulb costs 80 escape iterations per evaluation on the oracle side
+            got = gpu_render(rm, gpu_ctx, preset, accel, W, H, ang, algorithm=alg, time=tm)
+            want = cpu_render(oracle, preset, accel, W, H, ang, algorithm=alg, time=tm)
+            assert_same(got, want, "preset %d %s %s t=%g" % (preset, accel, alg, tm))
+
+
+def _random_forest(rng, n_roots):
+    """Nested dicts in the oracle's prims format: random operator trees over random leaves."""
+    def leaf():
+        kind = rng.choice(["sphere", "box", "torus"])
+        d = {"type": str(kind), "pos": [float(np.float32(v)) for v in rng.uniform(-1.2, 1.2, 3)],
+             "rot": [float(np.float32(v)) for v in rng.uniform(-3, 3, 3)] if rng.random() < 0.5 else None}
+        if kind == "sphere":
+            d["r"] = float(rng.uniform(0.1, 0.4))
+        elif kind == "box":
+            d["half"] = [float(np.float32(v)) for v in rng.uniform(0.05, 0.35, 3)]
+        else:
+            d["radius"] = float(rng.uniform(0.15, 0.4))
+        return d
+
+    def tree(depth):
+        if depth == 0 or rng.random() < 0.25:
+            return leaf()
+        op = rng.choice(["round", "smoothUnion", "smoothSub", "twist", "anim", "repetition"],
+                        p=[0.25, 0.3, 0.15, 0.15, 0.1, 0.05])
+        if op == "round":
+            return {"type": "round", "a": tree(depth - 1), "radius": float(rng.uniform(0.01, 0.15))}
+        if op == "twist":
+            return {"type": "twist", "a": tree(depth - 1), "amount": float(rng.uniform(0.5, 4))}
+        if op == "anim":
+            return {"type": "anim", "a": tree(depth - 1), "direction": [float(v) for v in rng.uniform(-1, 1, 3)],
+                    "amplitude": float(rng.uniform(0.1, 0.6)), "speed": float(rng.uniform(0.001, 0.01))}
+        if op == "repetition":
+            return {"type": "repetition", "a": tree(depth - 1), "spacing": [float(np.float32(v)) for v in rng.uniform(2.5, 4, 3)]}
+        return {"type": str(op), "a": tree(depth - 1), "b": tree(depth - 1), "k": float(rng.uniform(0.01, 0.3))}
+
+    return [tree(4) for _ in range(n_roots)]
+
+
+def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    for trial, n_roots in enumerate((1, 3, 7)):
+        forest = _random_forest(rng, n_roots)
+        for accel in ("None", "BVH", "Octree"):
+            osc = oracle.OracleScene(accel=accel, prims=forest)
+            osc.set_angles(0.2, -0.7)
+            want = osc.render(160, 100, time=500.0)
+            got = gpu_render(rm, gpu_ctx, None, accel, 160, 100, (0.2, -0.7), nodes=osc.nodes(), time=500.0)
+            assert_same(got, want, "forest %d %s" % (trial, accel))
+        sc = rm.Scene("BVH", ctx=gpu_ctx)
+        osc = oracle.OracleScene(accel="BVH", prims=forest)
+        sc.loadNodes(*osc.nodes())
+        sc.updateTime(250.0)
+        pts = rng.uniform(-2, 2, (300, 3)).astype(np.float32)
+        d, c = sc.getDistances(pts)
+        for k in range(0, 300, 3):
+            wd, wc = osc.distance(pts[k], time=250.0)
+            assert (d[k] == wd or (np.isnan(d[k]) and np.isnan(wd))) and c[k] == wc, (trial, k, d[k], wd)

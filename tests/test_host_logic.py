@@ -29,6 +29,7 @@ def test_struct_layouts_match_header(rm):
     assert C.sizeof(N.rm_job) == 72 and N.rm_job.camera_pitch.offset == 24 and N.rm_job.step_size.offset == 64
     assert C.sizeof(N.rm_scene_info) == 72
     assert C.sizeof(N.rm_diagnostics) == 32
+    assert C.sizeof(N.rm_node) == 128 and N.rm_node.params.offset == 80 and C.sizeof(N.rm_prim) == 104
 
 
 def test_string_defaulting_rules(rm):
@@ -58,7 +59,7 @@ def test_partition_rows_matches_main_ts(rm):
 
 def test_host_only_context_builds_scenes_like_the_oracle(rm, oracle):
     ctx = rm.Context(None)
-    for preset in (0, 1, 2, 3, 4, 5, 7, 8, 9):
+    for preset in range(19):  # 6 and 10-18: operator trees / Mandelbulb (bounds from the overridden getters)
         for accel, name in ((0, "None"), (1, "Octree"), (2, "BVH")):
             ctx.scene_from_preset(preset, accel)
             info = ctx.scene_info()
@@ -96,10 +97,18 @@ def test_camera_matches_oracle(rm, oracle):
 def test_error_codes_without_a_device(rm):
     from cpu_raymarcher_amd import _native as N
     ctx = rm.Context(None)
+    ctx.scene_from_preset(99, 2)  # scene.ts:39 clamps to preset 18 ("67")
+    assert ctx.scene_info()["n_prims"] == 2
+    ident = np.eye(4, dtype=np.float32).ravel()
+    chain = [(0, -1, -1, ident, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)]  # 20 nested Round operators
     with pytest.raises(rm.RmUnsupported):
-        ctx.scene_from_preset(99, 2)  # scene.ts:39 clamps to preset 18 ("67"): SDF operators, not native
-    with pytest.raises(rm.RmUnsupported):
-        ctx.scene_from_preset(6, 0)  # "Rounded Box": Round operator
+        ctx.scene_from_nodes(chain, [len(chain) - 1], 0)
+    ctx.scene_from_nodes(chain[:10], [9], 2)
+    assert ctx.scene_info()["n_prims"] == 1
+    with pytest.raises(rm.RmError):  # operands must precede their operator
+        ctx.scene_from_nodes([(10, 1, -1, None, [0.1]), (0, -1, -1, ident, [0.5])], [0], 0)
+    with pytest.raises(rm.RmError):
+        ctx.scene_from_nodes([(42, -1, -1, ident, [0.5])], [0], 0)
     ctx.scene_from_preset(-5, 2)  # clamps to preset 0
     assert ctx.scene_info()["n_prims"] == 1
     scene = rm.Scene("BVH", ctx=ctx)

@@ -46,6 +46,9 @@ def test_host_only_context_refuses_to_render(addon):
     dict(preset=3, accel="BVH", width=160, height=90, shader="sdf-heatmap", algorithm="adaptive-step-v3", overshootFactor=1.4),
     dict(preset=3, accel="Octree", width=160, height=90, shader="normal", algorithm="fixed-step"),
     dict(preset=5, accel="BVH", width=160, height=90, shader="phong", pitch=0.4, yaw=0.9),  # rotated torus
+    dict(preset=12, accel="None", width=160, height=90, shader="phong", time=2500.0),        # AnimatedTranslate: Job.time
+    dict(preset=16, accel="Octree", width=160, height=90, shader="normal", pitch=0.2, yaw=0.5),  # Round(Twist(Box))
+    dict(preset=13, accel="BVH", width=96, height=64, shader="iteration-heatmap", time=1000.0),  # Mandelbulb
 ])
 def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
@@ -57,7 +60,8 @@ def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
     sc = oracle.OracleScene(preset=cfg["preset"], accel=cfg["accel"])
     sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0))
     d, n, s, i = sc.render(W, H, y0, y1, algorithm=cfg.get("algorithm", "sphere-tracer"),
-                           overshoot_factor=cfg.get("overshootFactor"), step_size=cfg.get("stepSize"))
+                           overshoot_factor=cfg.get("overshootFactor"), step_size=cfg.get("stepSize"),
+                           time=cfg.get("time", 0.0))
     rgba = oracle.shade(cfg["shader"], d, n, s, i, W, y1 - y0)
     for name, arr in (("depth", d), ("normal", n), ("sdf", s), ("iters", i), ("rgba", rgba)):
         got = np.fromfile(str(tmp_path / "out" / (name + ".bin")), dtype=arr.dtype)
@@ -71,9 +75,9 @@ def test_node_worker_matches_oracle(addon, oracle, tmp_path, cfg):
 
 
 @pytest.mark.gpu
-def test_node_worker_reports_unsupported(addon, tmp_path):
-    cfg = dict(preset=6, accel="BVH", width=16, height=16, shader="normal")  # "Rounded Box": Round operator
+def test_node_worker_reports_errors(addon, tmp_path):
+    cfg = dict(preset=6, accel="BVH", width=16, height=0, shader="normal")  # height 0: u, v would divide by zero
     (tmp_path / "cfg.json").write_text(json.dumps(cfg))
     p = subprocess.run([NODE, os.path.join(ROOT, "native", "render_cli.js"), str(tmp_path / "cfg.json"),
                         str(tmp_path / "out")], stdout=subprocess.PIPE)
-    assert p.returncode == 3 and json.loads(p.stdout)["code"] == -2  # RM_E_UNSUPPORTED: host keeps its CPU path
+    assert p.returncode == 1 and json.loads(p.stdout)["code"] == -1  # RM_E_INVALID surfaces as an Error with .code

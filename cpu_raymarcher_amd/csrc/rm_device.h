@@ -153,27 +153,39 @@ __device__ __forceinline__ double prims_min(const RmSphere *spheres, const doubl
 // Sphere / Box / Torus .localSdf (sphere.ts:12-14, box.ts:13-30, torus.ts:14-25).
 __device__ __forceinline__ double prim_sdf_general(const RmPrim &q, const Vec3f &p) {
     const double x = p.x, y = p.y, z = p.z;
-    double w = q.m[3] * x + q.m[7] * y + q.m[11] * z + q.m[15];
-    if (!(w != 0.0)) w = 1.0;  // 0, -0 and NaN are falsy
-    const float lx = to_f32((q.m[0] * x + q.m[4] * y + q.m[8] * z + q.m[12]) / w);
-    const float ly = to_f32((q.m[1] * x + q.m[5] * y + q.m[9] * z + q.m[13]) / w);
-    const float lz = to_f32((q.m[2] * x + q.m[6] * y + q.m[10] * z + q.m[14]) / w);
-    if (q.type == 1) {
+    float lx, ly, lz;
+    if (q.type & 0x200) {  // pure translation: f32(x + t), see sphere_sdf
+        lx = p.x + q.m[12];
+        ly = p.y + q.m[13];
+        lz = p.z + q.m[14];
+    } else if (q.type & 0x100) {  // bottom row (0,0,0,1): w = 1 exactly for finite points, x / 1.0 = x
+        lx = to_f32(q.m[0] * x + q.m[4] * y + q.m[8] * z + q.m[12]);
+        ly = to_f32(q.m[1] * x + q.m[5] * y + q.m[9] * z + q.m[13]);
+        lz = to_f32(q.m[2] * x + q.m[6] * y + q.m[10] * z + q.m[14]);
+    } else {
+        double w = q.m[3] * x + q.m[7] * y + q.m[11] * z + q.m[15];
+        if (!(w != 0.0)) w = 1.0;  // 0, -0 and NaN are falsy
+        lx = to_f32((q.m[0] * x + q.m[4] * y + q.m[8] * z + q.m[12]) / w);
+        ly = to_f32((q.m[1] * x + q.m[5] * y + q.m[9] * z + q.m[13]) / w);
+        lz = to_f32((q.m[2] * x + q.m[6] * y + q.m[10] * z + q.m[14]) / w);
+    }
+    const int type = q.type & 0xFF;
+    if (type == 1) {
         const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - static_cast<double>(q.half[0]));
         const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - static_cast<double>(q.half[1]));
         const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - static_cast<double>(q.half[2]));
         const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;  // Math.max(q, 0)
-        const double outside = hypot3(o0, o1, o2);
+        const double outside = hypot3_shared_rcp(o0, o1, o2);
         const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);  // Math.max(q0, Math.max(q1, q2))
         const double inside = big < 0.f ? static_cast<double>(big) : 0.0;       // Math.min(., 0)
         return outside + inside;
     }
-    if (q.type == 2) {
+    if (type == 2) {
         const double dx = lx, dy = ly, dz = lz;
         const double qx = __builtin_sqrt(dx * dx + dz * dz) - q.a;
         return __builtin_sqrt(qx * qx + dy * dy) - q.b;
     }
-    return hypot3(lx, ly, lz) - q.a;
+    return hypot3_shared_rcp(lx, ly, lz) - q.a;
 }
 
 // BoundingBox.contains (boundingBox.ts:15-21)

@@ -13,9 +13,29 @@ namespace rmd {
 __device__ __forceinline__ double js_min_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
 __device__ __forceinline__ double js_max_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
 
-// vec3.transformMat4 into a Float32Array (w = w || 1.0)
-__device__ __forceinline__ void transform_mat4(const float *m, float fx, float fy, float fz, float &ox, float &oy, float &oz) {
+// vec3.transformMat4 into a Float32Array (w = w || 1.0).  `affine`: the host saw the bottom row
+// (m3, m7, m11, m15) = (0, 0, 0, 1) exactly; then w = 0*x + 0*y + 0*z + 1 is 1 for every finite point
+// (and NaN -> `|| 1.0` -> 1 for a non-finite one), and a division by 1.0 returns its numerator:
+// the three IEEE divisions are skipped with identical results.
+// `flags` bit 2 (of the two bits handed in): additionally the upper 3x3 block is exactly the identity
+// (translations, and the identity itself for the smooth unions): 1*x + 0*y + 0*z + t = x + t for every
+// finite point, signed zeros included (the trailing + t absorbs them), and f32(f64(x) + f64(t)) equals the
+// binary32 sum (double rounding is innocuous for + when the wide format has >= 2p+2 bits): one v_add_f32.
+__device__ __forceinline__ void transform_mat4(const float *m, int flags, float fx, float fy, float fz, float &ox, float &oy,
+                                               float &oz) {
+    if (flags & 4) {
+        ox = fx + m[12];
+        oy = fy + m[13];
+        oz = fz + m[14];
+        return;
+    }
     const double x = fx, y = fy, z = fz;
+    if (flags & 1) {
+        ox = to_f32(m[0] * x + m[4] * y + m[8] * z + m[12]);
+        oy = to_f32(m[1] * x + m[5] * y + m[9] * z + m[13]);
+        oz = to_f32(m[2] * x + m[6] * y + m[10] * z + m[14]);
+        return;
+    }
     double w = m[3] * x + m[7] * y + m[11] * z + m[15];
     if (!(w != 0.0)) w = 1.0;
     ox = to_f32((m[0] * x + m[4] * y + m[8] * z + m[12]) / w);
@@ -32,7 +52,7 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
     float z0 = p0, z1 = p1, z2 = p2;
     double dr = 1.0, r = 0.0;
     for (int i = 0; i < iterations; ++i) {
-        r = hypot3(z0, z1, z2);
+        r = hypot3_shared_rcp(z0, z1, z2);
         if (r > 2.0) break;
         double theta = js_atan2(z1, z0);
         double phi = js_asin(static_cast<double>(z2) / r);
@@ -50,7 +70,7 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
 }
 
 // One scene object: returns Primitive.sdf(p) of the root node.
-__device__ inline double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time) {
+__device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time) {
     float px[RM_PROG_MAX_SLOTS], py[RM_PROG_MAX_SLOTS], pz[RM_PROG_MAX_SLOTS];
     double val[RM_PROG_MAX_VALS];
     int sp = 0;
@@ -78,7 +98,7 @@ __device__ inline double program_sdf(const RmInstr *prog, int first, int count, 
             continue;
         }
         float lx, ly, lz;
-        transform_mat4(I.T, px[I.src], py[I.src], pz[I.src], lx, ly, lz);  // primitive.ts:34-35
+        transform_mat4(I.T, (I.flags & 1) | ((I.flags >> 2) & 1) << 2, px[I.src], py[I.src], pz[I.src], lx, ly, lz);  // primitive.ts:34-35
         if (op < 10) {  // leaves
             double d;
             if (op == 1) {  // box.ts:13-30
@@ -87,7 +107,7 @@ __device__ inline double program_sdf(const RmInstr *prog, int first, int count, 
                 const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - I.p[2]);
                 const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
                 const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
-                d = hypot3(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
+                d = hypot3_shared_rcp(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
             } else if (op == 2) {  // torus.ts:14-25
                 const double dx = lx, dy = ly, dz = lz;
                 const double qx = __builtin_sqrt(dx * dx + dz * dz) - I.p[0];
@@ -95,7 +115,7 @@ __device__ inline double program_sdf(const RmInstr *prog, int first, int count, 
             } else if (op == 3) {
                 d = mandelbulb_sdf(I.p, lx, ly, lz, time);
             } else {  // sphere.ts:12-14
-                d = hypot3(lx, ly, lz) - I.p[0];
+                d = hypot3_shared_rcp(lx, ly, lz) - I.p[0];
             }
             val[sp++] = d;
             continue;
@@ -108,7 +128,7 @@ __device__ inline double program_sdf(const RmInstr *prog, int first, int count, 
             wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(I.p[1] * offset)));
             wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(I.p[2] * offset)));
         } else {
-            transform_mat4(I.Tinv, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
+            transform_mat4(I.Tinv, ((I.flags >> 1) & 1) | ((I.flags >> 3) & 1) << 2, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
             if (op == 13) {  // twist.ts:21-33
                 const double a = I.p[0] * static_cast<double>(wy);
                 const double c = js_cos(a), s = js_sin(a);

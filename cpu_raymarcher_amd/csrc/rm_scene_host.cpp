@@ -628,6 +628,12 @@ bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, 
         RmPrim &q = s.prims[i];
         std::memcpy(q.m, d.m, sizeof q.m);
         q.type = d.type;
+        if (q.m[3] == 0.0f && q.m[7] == 0.0f && q.m[11] == 0.0f && q.m[15] == 1.0f) {
+            q.type |= 0x100;  // w == 1: no divide
+            if (q.m[0] == 1.0f && q.m[5] == 1.0f && q.m[10] == 1.0f && q.m[1] == 0.0f && q.m[2] == 0.0f && q.m[4] == 0.0f &&
+                q.m[6] == 0.0f && q.m[8] == 0.0f && q.m[9] == 0.0f)
+                q.type |= 0x200;  // pure translation
+        }
         q.half[0] = q.half[1] = q.half[2] = 0.0f;
         q.a = q.b = 0.0;
         double local_radius;
@@ -737,6 +743,12 @@ struct Forest {
         Mat4 inv = Mat4::identity();
         invert4(T[i].m, inv.m);  // stays identity when singular, like mat4.invert's untouched `out`
         std::memcpy(ins.Tinv, inv.m, sizeof ins.Tinv);
+        auto affine = [](const float *m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; };
+        auto shift = [&](const float *m) {  // pure translation: identity upper block on top of the affine bottom row
+            return affine(m) && m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f &&
+                   m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f;
+        };
+        ins.flags = (affine(ins.T) ? 1 : 0) | (affine(ins.Tinv) ? 2 : 0) | (shift(ins.T) ? 4 : 0) | (shift(ins.Tinv) ? 8 : 0);
         for (int k = 0; k < 6; ++k) ins.p[k] = d.params[k];
         if (d.type == 1 || d.type == 14 || d.type == 15)  // vec3 members are Float32Arrays
             for (int k = 0; k < 3; ++k) ins.p[k] = to_f32(d.params[k]);

@@ -50,7 +50,8 @@ struct RmSphere {
 // spheres use these records (v1 kernel); pure sphere scenes keep the compact RmSphere path.
 struct RmPrim {
     float m[16];
-    int32_t type;   // 0 sphere, 1 box, 2 torus
+    int32_t type;   // low byte: 0 sphere, 1 box, 2 torus; bit 8: m has the bottom row (0,0,0,1) (no w divide);
+                    // bit 9: m is a pure translation
     float half[3];  // box: halfSize (Float32Array, box.ts:8-11)
     double a, b;    // sphere: radius, -; torus: majorRadius, minorRadius
 };
@@ -69,7 +70,9 @@ struct RmInstr {
     float T[16];     // world -> local of the node (Primitive.transform)
     float Tinv[16];  // mat4.invert(T) as the operators recompute it per call (identity when singular)
     double p[6];
-    int32_t op, src, dst, pad;
+    int32_t op, src, dst;
+    int32_t flags;   // bit 0 / 1: T / Tinv has the bottom row (0,0,0,1) (transform_mat4 skips the w divide);
+                     // bit 2 / 3: T / Tinv is a pure translation (upper 3x3 identity): one f32 add per component
 };
 #define RM_PROG_MAX_SLOTS 16
 #define RM_PROG_MAX_VALS 16

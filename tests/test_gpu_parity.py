@@ -179,8 +179,12 @@ def test_empty_scene_and_bad_inputs(rm, gpu_ctx, oracle):
         assert_same(got, cpu_render(oracle, None, accel, 40, 30, spheres=empty), "empty scene " + accel)
     sc = rm.Scene("BVH", ctx=gpu_ctx)
     bufs = (np.zeros(16, np.uint8), np.zeros(48, np.uint8), np.zeros(16, np.uint16), np.zeros(16, np.uint16))
-    with pytest.raises(rm.RmUnsupported):
-        sc.loadPreset(10)  # "Smooth Union": SDF operator, not native
+    sc.loadPreset(10)  # every preset is native
+    with pytest.raises(rm.RmError):
+        rm.SphereTracer().runRaymarcher(sc, *bufs, 4, 4, float("inf"))  # non-finite Job.time
+    ident = np.eye(4, dtype=np.float32).ravel()
+    with pytest.raises(rm.RmUnsupported):  # deeper than the interpreter's position-slot file
+        sc.loadNodes([(0, -1, -1, ident, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)], [20])
     sc.camera.pitch = float("nan")
     with pytest.raises(rm.RmError):
         rm.SphereTracer().runRaymarcher(sc, *bufs, 4, 4)

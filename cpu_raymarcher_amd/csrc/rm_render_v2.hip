@@ -449,6 +449,22 @@ __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &ti
     return false;
 }
 
+// The kernel parameters live in the kernarg segment.  Sections that run once per 64 pixels (refill: ray
+// setup, pixel stores, tile queue) read what they need through this freshly laundered pointer, so the
+// ~60 SGPRs of camera matrix, output pointers and frame geometry are loaded there (s_load) and dead
+// again afterwards, instead of being hoisted out of the wave loop and spilled to VGPR lanes around it
+// (the first build carried 198 spilled SGPRs and reloaded ~100 of them per loop iteration).
+__device__ __forceinline__ RmRenderParams cold_params() {
+#if __HIP_DEVICE_COMPILE__  // the host pass only parses this body; address spaces exist in the device pass
+    typedef const __attribute__((address_space(4))) RmRenderParams *KernArgs;
+    KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();  // P is the kernel's only argument
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return RmRenderParams();
+#endif
+}
+
 template <int ACCEL, bool LDS>
 __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -496,24 +512,20 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
     L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
     const bool coop = P.coop != 0, filter = P.filter != 0;
 
-    TileQueue Q;
-    Q.counters = P.tile_counters;
-    Q.tile_w = P.tile_w;
-    Q.item_px = P.item_px;
-    Q.tile_h = P.item_px / P.tile_w;
-    const int rows = P.local_rows;
-    Q.tiles_x = (P.width + Q.tile_w - 1) / Q.tile_w;
-    Q.tiles_y = (rows + Q.tile_h - 1) / Q.tile_h;
+    const int item_px = P.item_px;
     // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
     int home = P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7);
     const int refill_at = P.refill_threshold;  // refill as soon as this many lanes are idle
 
     // ---- wave state: the tile being consumed ------------------------------------------------
-    int tile_col = 0, tile_row = 0, qpos = Q.item_px;  // qpos: next pixel of the current tile (item_px = used up)
+    int tile_col = 0, tile_row = 0, qpos = item_px;  // qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
 
     // ---- lane state ------------------------------------------------------------------------
-    Ray ray = make_ray(P, 0, P.y_start);
+    Ray ray;  // set by the first refill (every lane starts idle)
+    ray.o = {0.f, 0.f, 0.f};
+    ray.d = {0.f, 0.f, -1.f};
+    ray.od[0] = ray.od[1] = ray.od[2] = 0.0;
     RayInv ri;
     if (ACCEL == 2) ri = make_ray_inv(ray);
     uint32_t count = 0, iters = 0;
@@ -543,8 +555,16 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
         const unsigned long long idle = __ballot(phase == PH_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle >= refill_at || n_idle == 64) {
+            const RmRenderParams C = cold_params();
+            TileQueue Q;
+            Q.counters = C.tile_counters;
+            Q.tile_w = C.tile_w;
+            Q.item_px = C.item_px;
+            Q.tile_h = C.item_px / C.tile_w;
+            Q.tiles_x = (C.width + Q.tile_w - 1) / Q.tile_w;
+            Q.tiles_y = (C.local_rows + Q.tile_h - 1) / Q.tile_h;
             if (phase == PH_DONE && have_pixel) {
-                store_pixel(P, static_cast<size_t>(prow) * P.width + px, t, nx, ny, nz, count, iters);
+                store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;
             }
             if (!no_more && qpos >= Q.item_px) {
@@ -561,9 +581,9 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
                     const int sub = n >> 6, l = n & 63;
                     px = tile_col * Q.tile_w + (l % Q.tile_w);
                     prow = tile_row * Q.tile_h + sub * (64 / Q.tile_w) + (l / Q.tile_w);
-                    if (px < P.width && prow < rows) {
+                    if (px < C.width && prow < C.local_rows) {
                         have_pixel = true;
-                        ray = make_ray(P, px, row_to_y(P, prow));
+                        ray = make_ray(C, px, row_to_y(C, prow));
                         count = 0;
                         iters = 0;
                         loopi = 0;
@@ -591,7 +611,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
             }
         }
         if (no_more && !__any(phase != PH_DONE)) {
-            if (have_pixel) store_pixel(P, static_cast<size_t>(prow) * P.width + px, t, nx, ny, nz, count, iters);
+            if (have_pixel) {
+                const RmRenderParams C = cold_params();
+                store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
+            }
             break;
         }
         RM_T(0)

@@ -52,6 +52,23 @@ __device__ __forceinline__ double hypot3(float lx, float ly, float lz) {
 // paths, and r2 depends on y alone: computing it once and reusing it yields bit-identical
 // quotients with 14 instead of 30 instructions (one quarter-rate v_rcp_f64 instead of three).
 // tests/test_gpu_parity.py::test_device_hypot_is_v8_math_hypot compares the two on device.
+// sqrt for x in [1, 4): the compiler's IEEE expansion of __builtin_sqrt (v_rsq_f64, one coupled
+// Goldschmidt step, two residual corrections) without its input scaling for x < 2^-767 and its
+// zero / infinity fix-up, neither of which can trigger in this range: same ten instructions in the
+// middle, eight fewer around them, same correctly rounded result (rm_selftest_fastdiv compares).
+__device__ __forceinline__ double sqrt_unit_range(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return g;
+}
+
 __device__ __forceinline__ double hypot3_shared_rcp(float lx, float ly, float lz) {
     const double ax = __builtin_fabs(static_cast<double>(lx));
     const double ay = __builtin_fabs(static_cast<double>(ly));
@@ -74,7 +91,7 @@ __device__ __forceinline__ double hypot3_shared_rcp(float lx, float ly, float lz
     sum = next;
     const double sz = nz * nz - comp;
     sum = sum + sz;
-    return __builtin_sqrt(sum) * big;
+    return sqrt_unit_range(sum) * big;  // the largest scaled square is exactly 1: sum in [1, 3]
 }
 
 struct Vec3f {

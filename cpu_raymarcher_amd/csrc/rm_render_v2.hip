@@ -118,8 +118,15 @@ __device__ __forceinline__ float f32_upper(double v) {
 // lane alone: exact evaluation only for spheres whose conservative lower bound does not
 // exceed the best upper bound so far.  Skipped spheres satisfy exact > best >= result.
 __device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest) {
+    int k0 = 0;
+    if (closest >= RM_MAX_DIST && n > 0) {  // nothing to compare against yet: the first sphere is evaluated
+        const int id = ids ? ids[0] : 0;    // exactly either way (its bound cannot exceed MAX_DIST), skip the estimate
+        const double e = sphere_sdf_fast(S.spheres[id], S.radii[id], p);
+        closest = e < closest ? e : closest;
+        k0 = 1;
+    }
     float ub = f32_upper(closest);
-    for (int k = 0; k < n; ++k) {
+    for (int k = k0; k < n; ++k) {
         const int id = ids ? ids[k] : k;
         const RmSphere s = S.spheres[id];
         float err;
@@ -145,6 +152,30 @@ __device__ double lane_min_exact(const SceneView &S, const int32_t *ids, int n, 
 
 // all primitives for ONE point held by every lane (wave-uniform b); all 64 lanes take part
 __device__ double coop_all_prims(const SceneView &S, const Vec3f &b, int lane) {
+    if (S.n_prims <= 128) {  // two spheres per lane: the lower bounds of pass 1 stay in registers
+        const int j0 = lane, j1 = lane + 64;
+        const float inf = __builtin_inff();
+        float lb0 = inf, lb1 = inf, ub = 10.0f;
+        if (j0 < S.n_prims) {
+            float err;
+            const float a = sphere_sdf_estimate(S.spheres[j0], b, err);
+            lb0 = a - err;
+            ub = a + err < ub ? a + err : ub;
+        }
+        if (j1 < S.n_prims) {
+            float err;
+            const float a = sphere_sdf_estimate(S.spheres[j1], b, err);
+            lb1 = a - err;
+            ub = a + err < ub ? a + err : ub;
+        }
+        ub = wave_min_f32(ub);
+        const bool c0 = lb0 <= ub, c1 = lb1 <= ub;
+        double e0 = RM_MAX_DIST, e1 = RM_MAX_DIST;
+        if (c0) e0 = sphere_sdf_fast(S.spheres[j0], S.radii[j0], b);
+        double best = masked_min_f64(e0, __ballot(c0), RM_MAX_DIST);
+        if (c1) e1 = sphere_sdf_fast(S.spheres[j1], S.radii[j1], b);
+        return masked_min_f64(e1, __ballot(c1), best);
+    }
     float ub = 10.0f;
     for (int j = lane; j < S.n_prims; j += 64) {
         float err;

@@ -34,6 +34,7 @@ struct DeviceScene {
     RmPrim *prims = nullptr;
     RmInstr *prog = nullptr;
     int32_t *obj_ranges = nullptr;
+    RmSphereRec *oct_recs = nullptr;
 };
 
 }  // namespace
@@ -75,6 +76,7 @@ struct rm_ctx {
     int64_t opt_nn = 0;  // per-cell nearest-candidate lists: bit-exact but measured slower on C3 (3.71 vs 3.13 ms)
     int64_t opt_blocks_per_cu = 4;
     int64_t opt_refill = 64;
+    int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
     int64_t opt_hw_xcd = 1;
     int64_t opt_item_px = 64;
     unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
@@ -116,6 +118,7 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.prims);
     (void)hipFree(d.prog);
     (void)hipFree(d.obj_ranges);
+    (void)hipFree(d.oct_recs);
     d = DeviceScene();
 }
 
@@ -147,6 +150,7 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.prims, &ctx->dev.prims))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.prog, &ctx->dev.prog))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.obj_ranges, &ctx->dev.obj_ranges))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct_recs, &ctx->dev.oct_recs))) return rc;
     return RM_OK;
 }
 
@@ -336,6 +340,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.bvh_prims = ctx->dev.bvh_prims;
     p.oct = ctx->dev.oct;
     p.oct_prims = ctx->dev.oct_prims;
+    p.oct_recs = ctx->opt_recs ? ctx->dev.oct_recs : nullptr;
     return RM_OK;
 }
 
@@ -847,6 +852,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_coop = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "recs")) {
+        ctx->opt_recs = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "refill")) {
         if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "refill must be in [1, 64]");
         ctx->opt_refill = value;
@@ -888,6 +897,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "grid")) *value = ctx->opt_grid;
     else if (!std::strcmp(key, "nn")) *value = ctx->opt_nn;
     else if (!std::strcmp(key, "refill")) *value = ctx->opt_refill;
+    else if (!std::strcmp(key, "recs")) *value = ctx->opt_recs;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

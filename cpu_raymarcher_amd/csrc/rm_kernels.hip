@@ -102,6 +102,39 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
     }
 }
 
+// One leaf-ordered record against the running minimum (same filter as prims_min)
+__device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *rec, const Vec3f &p, double &closest, float &ub) {
+    const float dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
+    const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    const float err = (len + c.w + 1.0f) * 4e-6f;  // sphere_sdf_estimate
+    if ((len - c.w) - err <= ub) {
+        const double e = hypot3_shared_rcp(dx, dy, dz) - rec->radius;
+        if (e < closest) {
+            closest = e;
+            ub = __double2float_ru(e);
+        }
+    }
+}
+
+// min over a leaf's sphere records (RmSphereRec): four independent 16-B loads are issued before the
+// first estimate is consumed, so the L2 latency of a leaf is paid once per four spheres
+__device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, double closest) {
+    float ub = __double2float_ru(closest);
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const float4 c0 = *reinterpret_cast<const float4 *>(recs + k);
+        const float4 c1 = *reinterpret_cast<const float4 *>(recs + k + 1);
+        const float4 c2 = *reinterpret_cast<const float4 *>(recs + k + 2);
+        const float4 c3 = *reinterpret_cast<const float4 *>(recs + k + 3);
+        rec_consider(c0, recs + k, p, closest, ub);
+        rec_consider(c1, recs + k + 1, p, closest, ub);
+        rec_consider(c2, recs + k + 2, p, closest, ub);
+        rec_consider(c3, recs + k + 3, p, closest, ub);
+    }
+    for (; k < n; ++k) rec_consider(*reinterpret_cast<const float4 *>(recs + k), recs + k, p, closest, ub);
+    return closest;
+}
+
 // scene.ts:148-166 given the node findNode returned
 template <int GEN>
 __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec3f &p, uint32_t &count) {
@@ -109,7 +142,8 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
     const RmOctNode nd = P.oct[node];
     double closest = RM_MAX_DIST;
     if (nd.prim_count > 0) {
-        closest = list_min<GEN>(P, P.oct_prims + nd.prim_first, nd.prim_count, p, closest);
+        if (GEN == 0 && P.oct_recs && P.filter) closest = recs_min(P.oct_recs + nd.prim_first, nd.prim_count, p, closest);
+        else closest = list_min<GEN>(P, P.oct_prims + nd.prim_first, nd.prim_count, p, closest);
         count += static_cast<uint32_t>(nd.prim_count);
     } else if (nd.is_empty) {
         closest = min_dist(nd.min_distance * 0.99, closest);  // Math.min(closest, minDistance * safety)

@@ -454,6 +454,14 @@ static bool build_accel(HostScene &s, int n, std::string &err) {
         OctBuilder b{s};
         b.fill(0, all, root, 0);
         b.mark(0);
+        if (!s.general) {  // leaf-ordered sphere records for the device's leaf loops
+            s.oct_recs.resize(s.oct_prims.size());
+            for (size_t k = 0; k < s.oct_prims.size(); ++k) {
+                const int id = s.oct_prims[k];
+                const RmSphere &sp = s.spheres[id];
+                s.oct_recs[k] = RmSphereRec{sp.cx, sp.cy, sp.cz, sp.rf, s.radii[id], id, 0};
+            }
+        }
         std::memcpy(s.root_min, root.lo, sizeof root.lo);
         std::memcpy(s.root_max, root.hi, sizeof root.hi);
     }

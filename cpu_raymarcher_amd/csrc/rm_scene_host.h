@@ -57,6 +57,7 @@ struct HostScene {
     std::vector<uint16_t> nn_list;
     std::vector<RmOctNode> oct;
     std::vector<int32_t> oct_prims;
+    std::vector<RmSphereRec> oct_recs;  // oct_prims expanded to sphere records (sphere scenes)
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 };

@@ -35,6 +35,7 @@ struct DeviceScene {
     RmInstr *prog = nullptr;
     int32_t *obj_ranges = nullptr;
     RmSphereRec *oct_recs = nullptr;
+    int32_t *oct_lut = nullptr;
 };
 
 }  // namespace
@@ -77,6 +78,7 @@ struct rm_ctx {
     int64_t opt_blocks_per_cu = 4;
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
+    int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
     int64_t opt_hw_xcd = 1;
     int64_t opt_item_px = 64;
     unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
@@ -119,6 +121,7 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.prog);
     (void)hipFree(d.obj_ranges);
     (void)hipFree(d.oct_recs);
+    (void)hipFree(d.oct_lut);
     d = DeviceScene();
 }
 
@@ -151,6 +154,7 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.prog, &ctx->dev.prog))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.obj_ranges, &ctx->dev.obj_ranges))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_recs, &ctx->dev.oct_recs))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct_lut, &ctx->dev.oct_lut))) return rc;
     return RM_OK;
 }
 
@@ -341,6 +345,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.oct = ctx->dev.oct;
     p.oct_prims = ctx->dev.oct_prims;
     p.oct_recs = ctx->opt_recs ? ctx->dev.oct_recs : nullptr;
+    p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
     return RM_OK;
 }
 
@@ -746,6 +751,7 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     p.bvh_prims = ctx->dev.bvh_prims;
     p.oct = ctx->dev.oct;
     p.oct_prims = ctx->dev.oct_prims;
+    p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
     RM_HIP(ctx, hipMemcpyAsync(base, points_xyz, 12 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(ctx, rm_launch_distance(p, reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_dist),
                                    reinterpret_cast<uint32_t *>(base + o_cnt), ctx->stream));
@@ -856,6 +862,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_recs = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "lut")) {
+        ctx->opt_lut = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "refill")) {
         if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "refill must be in [1, 64]");
         ctx->opt_refill = value;
@@ -898,6 +908,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "nn")) *value = ctx->opt_nn;
     else if (!std::strcmp(key, "refill")) *value = ctx->opt_refill;
     else if (!std::strcmp(key, "recs")) *value = ctx->opt_recs;
+    else if (!std::strcmp(key, "lut")) *value = ctx->opt_lut;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

@@ -90,9 +90,22 @@ __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t
 // Octree.findNode (octree.ts:223-248): -1 when p is outside the root cube.  Children tile
 // their parent at the f32 centre and `contains` is inclusive, so the first child (index
 // order x + 2y + 4z) that contains p takes the low half on every axis where p <= centre.
+// With the cell table: on each axis the leaf is the cell k with b_k < p <= b_{k+1} (b_k = -10 + 0.3125 k,
+// exact in binary32; the lowest cell also takes p = -10), which is what "first child that contains p" selects.
+// k is guessed from a binary32 product (off by at most one cell) and corrected with exact compares.
+__device__ __forceinline__ int oct_cell(float v) {
+    int k = static_cast<int>((v + 10.0f) * 3.2f);
+    k = k < 0 ? 0 : (k > 63 ? 63 : k);
+    const float b = -10.0f + 0.3125f * static_cast<float>(k);  // exact
+    if (v <= b && k > 0) k -= 1;
+    else if (v > b + 0.3125f && k < 63) k += 1;
+    return k;
+}
+
 __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
     const RmOctNode *nodes = P.oct;
     if (!box_contains(nodes[0].lo, nodes[0].hi, p)) return -1;
+    if (P.oct_lut) return P.oct_lut[(oct_cell(p.z) * 64 + oct_cell(p.y)) * 64 + oct_cell(p.x)];
     int i = 0;
     for (;;) {
         const int first = nodes[i].first_child;

@@ -454,6 +454,28 @@ static bool build_accel(HostScene &s, int n, std::string &err) {
         OctBuilder b{s};
         b.fill(0, all, root, 0);
         b.mark(0);
+        {  // flat findNode table (see rm_scene_host.h); left empty if a leaf is not a box of whole cells
+            std::vector<int32_t> lut(64 * 64 * 64, -1);
+            bool ok = true;
+            for (size_t i = 0; i < s.oct.size() && ok; ++i) {
+                const RmOctNode &nd = s.oct[i];
+                if (nd.first_child >= 0) continue;
+                int k0[3], k1[3];
+                for (int a = 0; a < 3; ++a) {
+                    const double f0 = (double(nd.lo[a]) + 10.0) / 0.3125, f1 = (double(nd.hi[a]) + 10.0) / 0.3125;
+                    k0[a] = static_cast<int>(f0);
+                    k1[a] = static_cast<int>(f1);
+                    if (double(k0[a]) != f0 || double(k1[a]) != f1 || k0[a] < 0 || k1[a] > 64 || k0[a] >= k1[a]) ok = false;
+                }
+                if (!ok) break;
+                for (int z = k0[2]; z < k1[2]; ++z)
+                    for (int y = k0[1]; y < k1[1]; ++y)
+                        for (int x = k0[0]; x < k1[0]; ++x) lut[(size_t(z) * 64 + y) * 64 + x] = static_cast<int32_t>(i);
+            }
+            for (int32_t v : lut)
+                if (v < 0) ok = false;
+            if (ok) s.oct_lut = std::move(lut);
+        }
         if (!s.general) {  // leaf-ordered sphere records for the device's leaf loops
             s.oct_recs.resize(s.oct_prims.size());
             for (size_t k = 0; k < s.oct_prims.size(); ++k) {

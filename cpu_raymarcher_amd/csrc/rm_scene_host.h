@@ -58,6 +58,10 @@ struct HostScene {
     std::vector<RmOctNode> oct;
     std::vector<int32_t> oct_prims;
     std::vector<RmSphereRec> oct_recs;  // oct_prims expanded to sphere records (sphere scenes)
+    // Octree.findNode as one lookup: the tree is always the +-10 cube split at binary32 midpoints down to
+    // depth 6 (scene.ts:81-85, octree.ts:60), so every leaf is a box of whole 0.3125-cells of a 64^3 grid
+    // and every cell boundary -10 + 0.3125 k is exact in binary32.  oct_lut[(z*64 + y)*64 + x] = leaf node.
+    std::vector<int32_t> oct_lut;
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 };

@@ -149,6 +149,7 @@ struct RmRenderParams {
     const RmOctNode *oct;
     const int32_t *oct_prims;
     const RmSphereRec *oct_recs;  // parallel to oct_prims (sphere scenes only, else null)
+    const int32_t *oct_lut;       // 64^3 finest-level cells -> leaf node index (null: descend the tree)
     uint8_t *depth;
     uint8_t *normal;
     uint16_t *sdf;

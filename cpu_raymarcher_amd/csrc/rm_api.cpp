@@ -74,7 +74,8 @@ struct rm_ctx {
     int64_t opt_list_cap = 32;
     int64_t opt_coop = 1;
     int64_t opt_grid = 1;
-    int64_t opt_nn = 0;  // per-cell nearest-candidate lists: bit-exact but measured slower on C3 (3.71 vs 3.13 ms)
+    int64_t opt_nn = 2;  // per-cell nearest-candidate lists for the all-primitive fallback: 0 off, 1 on, 2 auto (scenes of
+                         // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
     int64_t opt_blocks_per_cu = 4;
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
@@ -309,7 +310,9 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
     p.filter = static_cast<int32_t>(ctx->opt_filter);
     p.variant = static_cast<int32_t>(ctx->opt_kernel);
-    if (p.variant == 0) p.variant = ctx->host.accel == RM_ACCEL_OCTREE ? 1 : 2;
+    // auto: the octree and small scenes (the 9-sphere grid: 0.59 ms against 0.75 ms at 1080p) run faster in the
+    // one-ray-per-lane kernel; the uniform wave loop pays off when leaves and fallbacks are expensive
+    if (p.variant == 0) p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 24) ? 1 : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
     if (ctx->host.general) p.variant = 1;                    // so do boxes, tori and rotated primitives
     p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
@@ -337,7 +340,12 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.nn_list = ctx->dev.nn_list;
     p.nn_cell_count = static_cast<int32_t>(ctx->host.nn_cells.size());
     p.nn_list_count = static_cast<int32_t>(ctx->host.nn_list.size());
-    p.use_nn = (p.use_grid && ctx->opt_nn && !ctx->host.nn_cells.empty()) ? 1 : 0;
+    const bool nn_on = ctx->opt_nn == 1 || (ctx->opt_nn == 2 && ctx->host.spheres.size() <= 512);
+    p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) {
+        p.nn_dim[k] = ctx->host.nn_dim[k];
+        p.nn_inv[k] = ctx->host.nn_inv[k];
+    }
     p.spheres = ctx->dev.spheres;
     p.radii = ctx->dev.radii;
     p.bvh = ctx->dev.bvh;
@@ -885,7 +893,8 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         return RM_OK;
     }
     if (!std::strcmp(key, "nn")) {
-        ctx->opt_nn = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, RM_E_INVALID, "nn must be 0 (off), 1 (on) or 2 (auto)");
+        ctx->opt_nn = value;
         return RM_OK;
     }
     if (!std::strcmp(key, "blocks_per_cu")) {

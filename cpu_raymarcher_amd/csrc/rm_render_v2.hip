@@ -236,7 +236,7 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     bool walk_tree = false;
-    int nn_cell = -1;  // grid cell of q when q lies inside the root box
+    bool in_root = false;
     if (need && use_grid) {
         // BVH.getPrimitivesAt through the leaf grid: the leaves listed for p's cell are a superset
         // of the leaves whose box contains p; each is re-tested with the reference's inclusive
@@ -246,8 +246,8 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             const int cx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
             const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
             const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
-            nn_cell = (cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx;
-            const uint32_t cell = S.pq_cells[nn_cell];
+            in_root = true;
+            const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
             const int ccnt = static_cast<int>(cell & 0xFFu);
             if (ccnt == 255) walk_tree = true;  // crowded cell: fall back to the tree walk below
             else {
@@ -285,11 +285,14 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
     }
     bool fallback = need && found == 0;
     bool served = false;
-    if (fallback && P.use_nn && nn_cell >= 0) {
+    if (fallback && P.use_nn && in_root) {
         // scene.ts:173 fallback through the cell's nearest-candidate list: every sphere that can
         // attain the minimum for a point of this cell is in the list (rm_scene_host.cpp), so the
         // minimum over the list equals the minimum over all N primitives; N are still counted.
-        const uint32_t cell = S.nn_cells[nn_cell];
+        const int nx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.nn_inv[0]), 0), P.nn_dim[0] - 1);
+        const int ny = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.nn_inv[1]), 0), P.nn_dim[1] - 1);
+        const int nz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.nn_inv[2]), 0), P.nn_dim[2] - 1);
+        const uint32_t cell = S.nn_cells[(nz * P.nn_dim[1] + ny) * P.nn_dim[0] + nx];  // global memory: ~1 MB of tables
         const int ccnt = static_cast<int>(cell & 0xFFu);
         if (ccnt != 255) {
             closest = prims_min<true, uint16_t>(S.spheres, S.radii, S.nn_list + (cell >> 8), ccnt, q, RM_MAX_DIST, true);
@@ -523,10 +526,6 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
             if (use_grid) {
                 S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
                 S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
-                if (P.use_nn) {
-                    S.nn_cells = stage(smem, off, P.nn_cells, P.nn_cell_count);
-                    S.nn_list = stage(smem, off, P.nn_list, P.nn_list_count);
-                }
             }
         } else if (ACCEL == 1) {
             S.oct = stage(smem, off, P.oct, P.oct_nodes);
@@ -768,7 +767,6 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
     if (p.accel == 2) {
         b += up(static_cast<size_t>(p.bvh_nodes) * sizeof(RmBvhNode)) + up(static_cast<size_t>(p.bvh_prim_count) * 4);
         if (p.use_grid) b += up(static_cast<size_t>(p.pq_cell_count) * 4) + up(static_cast<size_t>(p.pq_list_count) * 2 + 4);
-        if (p.use_grid && p.use_nn) b += up(static_cast<size_t>(p.nn_cell_count) * 4) + up(static_cast<size_t>(p.nn_list_count) * 2 + 4);
     } else if (p.accel == 1) {
         b += up(static_cast<size_t>(p.oct_nodes) * sizeof(RmOctNode)) + up(static_cast<size_t>(p.oct_prim_count) * 4);
     }

@@ -234,22 +234,33 @@ void build_point_query_grid(HostScene &s) {
     // min(10, min_j sdf_j(p)) for p in C, so evaluating only {j : lb_j <= U + margin} gives the
     // same minimum (min is order independent).  margin absorbs the difference between these
     // real-number bounds and the reference's rounded arithmetic (~1e-15) by many orders.
+    // The candidate grid is finer than the leaf grid (cell diagonal << sphere spacing keeps the lists at a
+    // handful of spheres): up to 48 cells per axis, bounded by the host work cells * n.
     const size_t n = s.spheres.size();
-    if (n == 0 || n >= 65536 || cells * n > 60000000ull) return;
-    s.nn_cells.assign(cells, 255);
+    if (n == 0 || n >= 65536) return;
+    int ng = 48;
+    while (ng > 4 && static_cast<unsigned long long>(ng) * ng * ng * n > 40000000ull) ng -= 4;
+    size_t ncells = 1;
+    for (int k = 0; k < 3; ++k) {
+        const double ext = double(s.root_max[k]) - double(s.root_min[k]);
+        s.nn_dim[k] = ext > 0 ? ng : 1;
+        s.nn_inv[k] = ext > 0 ? static_cast<float>(s.nn_dim[k] / ext) : 0.0f;
+        ncells *= static_cast<size_t>(s.nn_dim[k]);
+    }
+    s.nn_cells.assign(ncells, 255);
     const double margin = 1e-6;
     std::vector<double> lb(n);
-    for (int z = 0; z < s.pq_dim[2]; ++z)
-        for (int y = 0; y < s.pq_dim[1]; ++y)
-            for (int x = 0; x < s.pq_dim[0]; ++x) {
+    for (int z = 0; z < s.nn_dim[2]; ++z)
+        for (int y = 0; y < s.nn_dim[1]; ++y)
+            for (int x = 0; x < s.nn_dim[0]; ++x) {
                 const int ci[3] = {x, y, z};
                 double lo[3], hi[3];
                 for (int k = 0; k < 3; ++k) {
-                    const double w = s.pq_inv[k] > 0 ? 1.0 / double(s.pq_inv[k]) : 0.0;
-                    lo[k] = double(s.pq_origin[k]) + (ci[k] - 0.01) * w;
-                    hi[k] = double(s.pq_origin[k]) + (ci[k] + 1.01) * w;
-                    // border cells also receive the clamped indices of points outside the grid
-                    // range (only by rounding: the device tests the root box first), keep 1 % slack
+                    const double w = s.nn_inv[k] > 0 ? 1.0 / double(s.nn_inv[k]) : 0.0;
+                    // 3 % slack: the device's binary32 cell index is off by <= 1e-4 cell, and border cells
+                    // receive the clamped indices of points that round outside the grid range
+                    lo[k] = double(s.pq_origin[k]) + (ci[k] - 0.03) * w;
+                    hi[k] = double(s.pq_origin[k]) + (ci[k] + 1.03) * w;
                 }
                 double U = 10.0;
                 for (size_t j = 0; j < n; ++j) {
@@ -269,7 +280,7 @@ void build_point_query_grid(HostScene &s) {
                 std::vector<uint16_t> cand;
                 for (size_t j = 0; j < n; ++j)
                     if (lb[j] <= U + margin) cand.push_back(static_cast<uint16_t>(j));
-                const size_t c_idx = (static_cast<size_t>(z) * s.pq_dim[1] + y) * s.pq_dim[0] + x;
+                const size_t c_idx = (static_cast<size_t>(z) * s.nn_dim[1] + y) * s.nn_dim[0] + x;
                 if (cand.size() >= 255 || s.nn_list.size() + cand.size() >= (1u << 24)) continue;  // stays 255
                 s.nn_cells[c_idx] = static_cast<uint32_t>(s.nn_list.size() << 8) | static_cast<uint32_t>(cand.size());
                 s.nn_list.insert(s.nn_list.end(), cand.begin(), cand.end());

@@ -53,6 +53,8 @@ struct HostScene {
     std::vector<uint16_t> pq_list;
     // Same cells: spheres that can attain min_j Sphere.sdf for SOME point of the cell (the
     // all-primitive fallback of scene.ts:173 then only evaluates these).  count 255 = no list.
+    int nn_dim[3] = {0, 0, 0};
+    float nn_inv[3] = {0, 0, 0};
     std::vector<uint32_t> nn_cells;
     std::vector<uint16_t> nn_list;
     std::vector<RmOctNode> oct;

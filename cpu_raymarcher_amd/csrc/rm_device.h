@@ -116,12 +116,21 @@ __device__ __forceinline__ double sphere_sdf_fast(const RmSphere &s, double radi
     return hypot3_shared_rcp(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
 }
 
+// A binary32 value >= v for the filter's running upper bound: round to nearest, then add more than the
+// rounding error (2^-24 |v|, or half the smallest denormal).  One ulp looser than a directed rounding, three
+// instructions instead of the fourteen of __double2float_ru's emulation.
+__device__ __forceinline__ float f32_upper_bound(double v) {
+    const float f = static_cast<float>(v);
+    return f + (__builtin_fabsf(f) * 1.2e-7f + 1e-30f);
+}
+
 // Conservative binary32 estimate of the same distance: |estimate - exact| <= err.
-// Error budget: 2^-24 (3.5 len + r + |a|) <= 2.7e-7 (len + r); err is ~15x that, which
-// also absorbs the roundings of the +/- err comparisons themselves.
+// Error budget: 2^-24 (4.5 len + r + |a|) <= 3.3e-7 (len + r) with the raw v_sqrt_f32 (1 ulp; the IEEE
+// expansion of sqrtf costs 15 more instructions and buys nothing here); err is ~12x that, which also
+// absorbs the roundings of the +/- err comparisons themselves.
 __device__ __forceinline__ float sphere_sdf_estimate(const RmSphere &s, const Vec3f &p, float &err) {
     const float dx = p.x - s.cx, dy = p.y - s.cy, dz = p.z - s.cz;
-    const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
     err = (len + s.rf + 1.0f) * 4e-6f;
     return len - s.rf;
 }
@@ -149,7 +158,7 @@ __device__ __forceinline__ double prims_min(const RmSphere *spheres, const doubl
         }
         return closest;
     }
-    float ub = __double2float_ru(closest);
+    float ub = f32_upper_bound(closest);
     for (int k = 0; k < n; ++k) {
         const int id = ids ? ids[k] : k;
         const RmSphere s = spheres[id];
@@ -159,7 +168,7 @@ __device__ __forceinline__ double prims_min(const RmSphere *spheres, const doubl
             const double e = FAST ? sphere_sdf_fast(s, radii[id], p) : sphere_sdf(s, radii[id], p);
             if (e < closest) {
                 closest = e;
-                ub = __double2float_ru(e);
+                ub = f32_upper_bound(e);
             }
         }
     }

@@ -118,13 +118,13 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
 // One leaf-ordered record against the running minimum (same filter as prims_min)
 __device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *rec, const Vec3f &p, double &closest, float &ub) {
     const float dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
-    const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
     const float err = (len + c.w + 1.0f) * 4e-6f;  // sphere_sdf_estimate
     if ((len - c.w) - err <= ub) {
         const double e = hypot3_shared_rcp(dx, dy, dz) - rec->radius;
         if (e < closest) {
             closest = e;
-            ub = __double2float_ru(e);
+            ub = f32_upper_bound(e);
         }
     }
 }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *
 // min over a leaf's sphere records (RmSphereRec): four independent 16-B loads are issued before the
 // first estimate is consumed, so the L2 latency of a leaf is paid once per four spheres
 __device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, double closest) {
-    float ub = __double2float_ru(closest);
+    float ub = f32_upper_bound(closest);
     int k = 0;
     for (; k + 4 <= n; k += 4) {
         const float4 c0 = *reinterpret_cast<const float4 *>(recs + k);

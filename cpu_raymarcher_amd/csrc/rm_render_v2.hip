@@ -111,7 +111,7 @@ __device__ __forceinline__ float readlane_f32(float v, int src_lane) {
 
 // round-up conversion so that the binary32 value is an upper bound of the double
 __device__ __forceinline__ float f32_upper(double v) {
-    return __double2float_ru(v);
+    return f32_upper_bound(v);
 }
 
 // min over an id list (or 0..n-1 when ids == nullptr) of the exact sphere distance, one
@@ -523,10 +523,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
         if (ACCEL == 2) {
             S.nodes = stage(smem, off, P.bvh, P.bvh_nodes);
             S.bvh_prims = stage(smem, off, P.bvh_prims, P.bvh_prim_count);
-            if (use_grid) {
-                S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
-                S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
-            }
+            // staged unconditionally: a pointer that is LDS on one path and global on the other is a generic
+            // pointer, and every list read in the leaf loop became a flat_load with a full s_waitcnt
+            S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
+            S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
         } else if (ACCEL == 1) {
             S.oct = stage(smem, off, P.oct, P.oct_nodes);
             S.oct_prims = stage(smem, off, P.oct_prims, P.oct_prim_count);
@@ -766,7 +766,7 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
     size_t b = 0;
     if (p.accel == 2) {
         b += up(static_cast<size_t>(p.bvh_nodes) * sizeof(RmBvhNode)) + up(static_cast<size_t>(p.bvh_prim_count) * 4);
-        if (p.use_grid) b += up(static_cast<size_t>(p.pq_cell_count) * 4) + up(static_cast<size_t>(p.pq_list_count) * 2 + 4);
+        b += up(static_cast<size_t>(p.pq_cell_count) * 4) + up(static_cast<size_t>(p.pq_list_count) * 2 + 4);
     } else if (p.accel == 1) {
         b += up(static_cast<size_t>(p.oct_nodes) * sizeof(RmOctNode)) + up(static_cast<size_t>(p.oct_prim_count) * 4);
     }

@@ -253,6 +253,7 @@ __device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const
 struct RayInv {
     double inv[3];
     bool par[3];
+    bool any_par;  // some axis has |d| < 1e-10 (only the rays through the image's centre column / row)
 };
 
 __device__ __forceinline__ RayInv make_ray_inv(const Ray &r) {
@@ -263,11 +264,24 @@ __device__ __forceinline__ RayInv make_ray_inv(const Ray &r) {
         ri.par[a] = __builtin_fabs(static_cast<double>(d[a])) < 1e-10;
         ri.inv[a] = ri.par[a] ? 0.0 : 1.0 / static_cast<double>(d[a]);
     }
+    ri.any_par = ri.par[0] || ri.par[1] || ri.par[2];
     return ri;
 }
 
 __device__ __forceinline__ bool slab_inv(const float lo[3], const float hi[3], const Ray &r, const RayInv &ri,
                                          double &tEnter, double &tExit) {
+    if (__ballot(ri.any_par) == 0) {
+        // No active lane has a parallel axis (the normal case): straight-line code.  tMin only grows and tMax
+        // only shrinks, so the per-axis `if (tMin > tMax) return null` of the reference equals one test at the end.
+        const double ax = (static_cast<double>(lo[0]) - r.od[0]) * ri.inv[0], bx = (static_cast<double>(hi[0]) - r.od[0]) * ri.inv[0];
+        const double ay = (static_cast<double>(lo[1]) - r.od[1]) * ri.inv[1], by = (static_cast<double>(hi[1]) - r.od[1]) * ri.inv[1];
+        const double az = (static_cast<double>(lo[2]) - r.od[2]) * ri.inv[2], bz = (static_cast<double>(hi[2]) - r.od[2]) * ri.inv[2];
+        const double tMin = __builtin_fmax(__builtin_fmax(__builtin_fmin(ax, bx), __builtin_fmin(ay, by)), __builtin_fmin(az, bz));
+        const double tMax = __builtin_fmin(__builtin_fmin(__builtin_fmax(ax, bx), __builtin_fmax(ay, by)), __builtin_fmax(az, bz));
+        tEnter = tMin;
+        tExit = tMax;
+        return !(tMin > tMax);
+    }
     double tMin = -__builtin_inf(), tMax = __builtin_inf();
     const float o[3] = {r.o.x, r.o.y, r.o.z};
 #pragma unroll

@@ -342,6 +342,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.nn_list_count = static_cast<int32_t>(ctx->host.nn_list.size());
     const bool nn_on = ctx->opt_nn == 1 || (ctx->opt_nn == 2 && ctx->host.spheres.size() <= 512);
     p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
+    p.leaf_order = ctx->host.leaf_order ? 1 : 0;
     for (int k = 0; k < 3; ++k) {
         p.nn_dim[k] = ctx->host.nn_dim[k];
         p.nn_inv[k] = ctx->host.nn_inv[k];

@@ -117,17 +117,18 @@ __device__ __forceinline__ float f32_upper(double v) {
 // min over an id list (or 0..n-1 when ids == nullptr) of the exact sphere distance, one
 // lane alone: exact evaluation only for spheres whose conservative lower bound does not
 // exceed the best upper bound so far.  Skipped spheres satisfy exact > best >= result.
-__device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest) {
+__device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest,
+                                    int base = 0) {
     int k0 = 0;
     if (closest >= RM_MAX_DIST && n > 0) {  // nothing to compare against yet: the first sphere is evaluated
-        const int id = ids ? ids[0] : 0;    // exactly either way (its bound cannot exceed MAX_DIST), skip the estimate
+        const int id = ids ? ids[0] : base;  // exactly either way (its bound cannot exceed MAX_DIST), skip the estimate
         const double e = sphere_sdf_fast(S.spheres[id], S.radii[id], p);
         closest = e < closest ? e : closest;
         k0 = 1;
     }
     float ub = f32_upper(closest);
     for (int k = k0; k < n; ++k) {
-        const int id = ids ? ids[k] : k;
+        const int id = ids ? ids[k] : base + k;
         const RmSphere s = S.spheres[id];
         float err;
         const float a = sphere_sdf_estimate(s, p, err);
@@ -142,9 +143,9 @@ __device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int 
     return closest;
 }
 
-__device__ double lane_min_exact(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest) {
+__device__ double lane_min_exact(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest, int base = 0) {
     for (int k = 0; k < n; ++k) {
-        const int id = ids ? ids[k] : k;
+        const int id = ids ? ids[k] : base + k;
         closest = min_dist(sphere_sdf_fast(S.spheres[id], S.radii[id], p), closest);
     }
     return closest;
@@ -256,8 +257,9 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
                     const RmBvhNode node = S.nodes[lst[e]];
                     if (!box_contains(node.lo, node.hi, q)) continue;
                     const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
-                    closest = (filter && cnt >= 2) ? lane_min_filtered(S, S.bvh_prims + first, cnt, q, closest)
-                                                   : lane_min_exact(S, S.bvh_prims + first, cnt, q, closest);
+                    const int32_t *ids = P.leaf_order ? nullptr : S.bvh_prims + first;
+                    closest = (filter && cnt >= 2) ? lane_min_filtered(S, ids, cnt, q, closest, first)
+                                                   : lane_min_exact(S, ids, cnt, q, closest, first);
                     found += static_cast<uint32_t>(cnt);
                 }
             }
@@ -277,8 +279,9 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
                 continue;
             }
             const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
-            closest = (filter && cnt >= 2) ? lane_min_filtered(S, S.bvh_prims + first, cnt, q, closest)
-                                           : lane_min_exact(S, S.bvh_prims + first, cnt, q, closest);
+            const int32_t *ids = P.leaf_order ? nullptr : S.bvh_prims + first;
+            closest = (filter && cnt >= 2) ? lane_min_filtered(S, ids, cnt, q, closest, first)
+                                           : lane_min_exact(S, ids, cnt, q, closest, first);
             found += static_cast<uint32_t>(cnt);
             i = node.skip;
         }

@@ -532,7 +532,34 @@ bool build_scene(HostScene &s, const float *centers, const double *radii, int n,
         }
     }
     s.world_pos.assign(centers, centers + 3 * size_t(n));
-    return build_accel(s, n, err);
+    if (!build_accel(s, n, err)) return false;
+    // BVH: every sphere lives in exactly one leaf, so the device arrays can be permuted into leaf order; a leaf's
+    // spheres are then spheres[first .. first+count) and the id indirection (one dependent LDS read per sphere)
+    // disappears.  min() and the counters do not depend on the order.
+    if (s.accel == 2 && s.bvh_prims.size() == size_t(n) && n > 0) {
+        std::vector<RmSphere> sp(n);
+        std::vector<double> rd(n);
+        std::vector<int32_t> pos(n, -1);
+        bool perm = true;
+        for (int k = 0; k < n; ++k) {
+            const int id = s.bvh_prims[k];
+            if (id < 0 || id >= n || pos[id] >= 0) {
+                perm = false;
+                break;
+            }
+            pos[id] = k;
+            sp[k] = s.spheres[id];
+            rd[k] = s.radii[id];
+        }
+        if (perm) {
+            s.spheres.swap(sp);
+            s.radii.swap(rd);
+            std::iota(s.bvh_prims.begin(), s.bvh_prims.end(), 0);
+            for (uint16_t &e : s.nn_list) e = static_cast<uint16_t>(pos[e]);
+            s.leaf_order = true;
+        }
+    }
+    return true;
 }
 
 // ---- general primitives -----------------------------------------------------------------------

@@ -38,6 +38,7 @@ struct HostScene {
     std::vector<int32_t> obj_ranges;  // (first, count) per scene object
     std::vector<RmPrim> prims;
     std::vector<float> world_pos; // Primitive.getWorldPosition() per primitive (BVH sort key)
+    bool leaf_order = false;      // BVH sphere scenes: spheres / radii are stored in leaf order, bvh_prims is 0..n-1
     std::vector<RmSphere> spheres;
     std::vector<double> radii;
     std::vector<float> prim_lo, prim_hi;  // padded AABBs, 3 floats per primitive

@@ -133,6 +133,7 @@ struct RmRenderParams {
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;
+    int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
     float nn_inv[3];
     int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)

@@ -177,14 +177,16 @@ __device__ __forceinline__ double scene_distance(const RmRenderParams &P, const 
 // (bvh.ts:126-178) and walks the list with an index (bvh.ts:204-240).  This returns the
 // element that follows key (keyT, keyOrd) in exactly that order -- ascending tEnter, ties
 // in traversal order -- by one stackless traversal, so no per-ray list is stored.
-__device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, double keyT, int keyOrd, Interval &out) {
+__device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, const RayInv &ri, double keyT, int keyOrd,
+                                  Interval &out) {
     bool have = false;
     int i = 0;
     const int n = P.bvh_nodes;
     while (i < n) {
         const RmBvhNode node = P.bvh[i];
         double tE, tX;
-        if (!slab(node.lo, node.hi, r, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
+        // 1 / direction[i] (boundingBox.ts:78) is the same quotient for every box: computed once per ray
+        if (!slab_inv(node.lo, node.hi, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
             i = node.skip;
             continue;
         }
@@ -250,8 +252,10 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
     double t = 0.0;
     Interval cur;
     bool haveCur = false;
+    RayInv ri;
     if (ACCEL == 2) {
-        haveCur = bvh_next_interval(P, ray, -__builtin_inf(), -1, cur);  // onRayMarchStart
+        ri = make_ray_inv(ray);
+        haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);  // onRayMarchStart
         if (!haveCur) return RM_MAX_DIST;                                // bvh.ts:190-192
     }
     for (int i = 0; i < RM_MAX_STEPS; ++i) {
@@ -267,7 +271,7 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
             if (t < cur.tEnter) skip = cur.tEnter - t;
             else if (t > cur.tExit) {
                 const Interval prev = cur;
-                haveCur = bvh_next_interval(P, ray, prev.tEnter, prev.ord, cur);  // idx++
+                haveCur = bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);  // idx++
                 if (!haveCur) return RM_MAX_DIST;
                 if (cur.tEnter > t) skip = cur.tEnter - t;
             }
@@ -315,8 +319,10 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     bool hit = false;
     Interval cur;
     bool haveCur = false;
+    RayInv ri;
     if (ACCEL == 2) {
-        haveCur = bvh_next_interval(P, ray, -__builtin_inf(), -1, cur);
+        ri = make_ray_inv(ray);
+        haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);
         if (!haveCur) return RM_MAX_DIST;
     }
     for (int i = 0; i < max_steps; ++i) {
@@ -328,7 +334,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
             if (t < cur.tEnter) skip = cur.tEnter - t;
             else if (t > cur.tExit) {
                 const Interval prev = cur;
-                haveCur = bvh_next_interval(P, ray, prev.tEnter, prev.ord, cur);
+                haveCur = bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);
                 if (!haveCur) return RM_MAX_DIST;
                 if (cur.tEnter > t) skip = cur.tEnter - t;
             }
@@ -481,8 +487,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const 
         const int64_t nvec = n / 8;
         const uint4 *s4 = reinterpret_cast<const uint4 *>(sdf);
         const uint4 *i4 = reinterpret_cast<const uint4 *>(iters);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            const uint4 a = s4[v], b = i4[v];
+        auto eat = [&](const uint4 a, const uint4 b) {
             const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -494,7 +499,17 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint16_t *sdf, const 
                 mn = hi < mn ? hi : mn;
                 it += (bw[k] & 0xFFFFu) + (bw[k] >> 16);
             }
+        };
+        int64_t v = tid;
+        for (; v + 3 * nthreads < nvec; v += 4 * nthreads) {  // eight 16-B loads in flight per lane
+            const uint4 a0 = s4[v], b0 = i4[v], a1 = s4[v + nthreads], b1 = i4[v + nthreads];
+            const uint4 a2 = s4[v + 2 * nthreads], b2 = i4[v + 2 * nthreads], a3 = s4[v + 3 * nthreads], b3 = i4[v + 3 * nthreads];
+            eat(a0, b0);
+            eat(a1, b1);
+            eat(a2, b2);
+            eat(a3, b3);
         }
+        for (; v < nvec; v += nthreads) eat(s4[v], i4[v]);
         done = nvec * 8;
     }
     for (int64_t i = done + tid; i < n; i += nthreads) {
@@ -652,7 +667,7 @@ hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t 
                             hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n / 8 + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 256) blocks = 256;  // one atomic set per workgroup on one cache line: ~12 ns each, they serialise
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sdf, iters, n, acc);
     return hipGetLastError();

@@ -212,7 +212,12 @@ int scene_n_prims(const rm_ctx *ctx) {
 
 // which primitive representation the kernels read (RmRenderParams::general)
 void fill_scene_repr(const rm_ctx *ctx, RmRenderParams &p) {
-    p.general = ctx->host.program ? 2 : (ctx->host.general ? 1 : 0);
+    p.general = ctx->host.general ? 1 : 0;
+    if (ctx->host.program) {
+        p.general = 2;
+        for (const RmInstr &ins : ctx->host.prog)
+            if (ins.op == 3) p.general = 3;  // Mandelbulb leaf: the instantiation that carries the fdlibm code
+    }
     p.prims = ctx->dev.prims;
     p.prog = ctx->dev.prog;
     p.obj_ranges = ctx->dev.obj_ranges;

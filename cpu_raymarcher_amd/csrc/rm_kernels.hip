@@ -32,14 +32,14 @@ using namespace rmd;
 // GEN is a compile-time property of the kernel instantiation: a run-time `if (P.general)` in
 // front of the sphere loop changed the results of render_kernel<0, true> (lane-grouping
 // dependent wrong normals with hipcc 7.2), so the two representations never share a function body.
-// GEN: 0 RmSphere records, 1 RmPrim records, 2 expression programs (rm_program.h).
+// GEN: 0 RmSphere records, 1 RmPrim records, 2 expression programs (rm_program.h), 3 programs with a Mandelbulb.
 template <int GEN>
 __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_t *ids, int n, const Vec3f &p,
                                            double closest) {
-    if (GEN == 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
+    if (GEN >= 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
         for (int k = 0; k < n; ++k) {
             const int obj = ids ? ids[k] : k;
-            closest = js_min_nan(program_sdf(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time), closest);
+            closest = js_min_nan(program_sdf<GEN == 3>(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time), closest);
         }
         return closest;
     }
@@ -636,7 +636,9 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
 #define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, 0, stream, p)
 #define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G); else if (p.accel == 1) RM_V1(1, O, G); else RM_V1(0, O, G); }
-    if (p.general == 2) {
+    if (p.general == 3) {
+        if (p.algorithm == 0) RM_V1A(false, 3) else RM_V1A(true, 3)
+    } else if (p.general == 2) {
         if (p.algorithm == 0) RM_V1A(false, 2) else RM_V1A(true, 2)
     } else if (p.general) {
         if (p.algorithm == 0) RM_V1A(false, 1) else RM_V1A(true, 1)
@@ -678,7 +680,8 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
 #define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, 0, stream, p, points, n, dist, count)
-    if (p.general == 2) { if (p.accel == 2) RM_DK(2, 2); else if (p.accel == 1) RM_DK(1, 2); else RM_DK(0, 2); }
+    if (p.general == 3) { if (p.accel == 2) RM_DK(2, 3); else if (p.accel == 1) RM_DK(1, 3); else RM_DK(0, 3); }
+    else if (p.general == 2) { if (p.accel == 2) RM_DK(2, 2); else if (p.accel == 1) RM_DK(1, 2); else RM_DK(0, 2); }
     else if (p.general) { if (p.accel == 2) RM_DK(2, 1); else if (p.accel == 1) RM_DK(1, 1); else RM_DK(0, 1); }
     else { if (p.accel == 2) RM_DK(2, 0); else if (p.accel == 1) RM_DK(1, 0); else RM_DK(0, 0); }
 #undef RM_DK

@@ -69,7 +69,10 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
     return 0.5 * js_log(r) * r / dr;
 }
 
-// One scene object: returns Primitive.sdf(p) of the root node.
+// One scene object: returns Primitive.sdf(p) of the root node.  MB = the scene has a Mandelbulb leaf: its fdlibm
+// code doubles the register need (200 against 106 VGPRs), so scenes without one get an instantiation that runs
+// four waves per SIMD instead of two.
+template <bool MB>
 __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time) {
     float px[RM_PROG_MAX_SLOTS], py[RM_PROG_MAX_SLOTS], pz[RM_PROG_MAX_SLOTS];
     double val[RM_PROG_MAX_VALS];
@@ -112,7 +115,7 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
                 const double dx = lx, dy = ly, dz = lz;
                 const double qx = __builtin_sqrt(dx * dx + dz * dz) - I.p[0];
                 d = __builtin_sqrt(qx * qx + dy * dy) - I.p[1];
-            } else if (op == 3) {
+            } else if (MB && op == 3) {
                 d = mandelbulb_sdf(I.p, lx, ly, lz, time);
             } else {  // sphere.ts:12-14
                 d = hypot3_shared_rcp(lx, ly, lz) - I.p[0];

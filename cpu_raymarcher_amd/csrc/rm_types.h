@@ -137,7 +137,7 @@ struct RmRenderParams {
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
     float nn_inv[3];
     int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)
-    int32_t general;     // 0: RmSphere records; 1: RmPrim records (`prims`); 2: expression programs (`prog`)
+    int32_t general;     // 0: RmSphere records; 1: RmPrim records (`prims`); 2: expression programs (`prog`); 3: programs with a Mandelbulb
     int32_t reserved3;
     const RmPrim *prims;
     const RmInstr *prog;         // general == 2: instructions of every scene object, concatenated

@@ -442,6 +442,167 @@ __device__ inline double js_pow(double x, double y) {
     return s * z;
 }
 
+/* The two halves of js_pow for an ordinary base (finite, > 0, not 1) and an ordinary exponent (finite, not 0, +-1, 2,
+ * 0.5, |y| <= 2^31), as separate functions with the identical arithmetic: the Mandelbulb raises the same r to
+ * power - 1 and to power (mandelbulb.ts:61-64), and the extended-precision log2 of the base is the larger half. */
+__device__ inline void jm_pow_log2(double ax, int32_t ix, double &t1, double &t2) {
+    const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01},
+                 dp_l[2] = {0.0, 1.35003920212974897128e-08};
+    constexpr double two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300,
+                        L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
+                        L4 = 2.72728123808534006489e-01, L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                        lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01, lg2_l = -1.90465429995776804525e-09,
+                        ovt = 8.0085662595372944372e-0017, cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+                        cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00,
+                        ivln2_h = 1.44269502162933349609e+00, ivln2_l = 1.92596299112661746887e-08;
+    double z_h, z_l, p_h, p_l, r, t, u, v;
+    int32_t j, k, n;
+    (void)huge; (void)tiny; (void)P1; (void)P2; (void)P3; (void)P4; (void)P5; (void)lg2; (void)lg2_h; (void)lg2_l; (void)ovt;
+    (void)ivln2; (void)ivln2_h; (void)ivln2_l;
+    {
+        double ss, s2, s_h, s_l, t_h, t_l;
+        n = 0;
+        if (ix < 0x00100000) { ax *= two53; n -= 53; ix = jm_hi(ax); }
+        n += (ix >> 20) - 0x3ff;
+        j = ix & 0x000fffff;
+        ix = j | 0x3ff00000;
+        if (j <= 0x3988E) k = 0;
+        else if (j < 0xBB67A) k = 1;
+        else { k = 0; n += 1; ix -= 0x00100000; }
+        ax = jm_set_hi(ax, ix);
+        u = ax - bp[k];
+        v = 1.0 / (ax + bp[k]);
+        ss = u * v;
+        s_h = jm_set_lo(ss, 0);
+        t_h = jm_words(((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18), 0);
+        t_l = ax - (t_h - bp[k]);
+        s_l = v * ((u - s_h * t_h) - s_h * t_l);
+        s2 = ss * ss;
+        r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+        r += s_l * (s_h + ss);
+        s2 = s_h * s_h;
+        t_h = jm_set_lo(3.0 + s2 + r, 0);
+        t_l = r - ((t_h - 3.0) - s2);
+        u = s_h * t_h;
+        v = s_l * t_h + t_l * ss;
+        p_h = jm_set_lo(u + v, 0);
+        p_l = v - (p_h - u);
+        z_h = cp_h * p_h;
+        z_l = cp_l * p_h + p_l * cp + dp_l[k];
+        t = (double)n;
+        t1 = jm_set_lo(((z_h + z_l) + dp_h[k]) + t, 0);
+        t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+    }
+}
+
+__device__ inline double jm_pow_exp2(double y, double t1, double t2) {
+    const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01},
+                 dp_l[2] = {0.0, 1.35003920212974897128e-08};
+    constexpr double two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300,
+                        L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
+                        L4 = 2.72728123808534006489e-01, L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                        lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01, lg2_l = -1.90465429995776804525e-09,
+                        ovt = 8.0085662595372944372e-0017, cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+                        cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00,
+                        ivln2_h = 1.44269502162933349609e+00, ivln2_l = 1.92596299112661746887e-08;
+    const double s = 1.0;
+    double z, p_h, p_l, y1, r, t, u, v, w;
+    int32_t i, j, k, n;
+    (void)bp; (void)dp_h; (void)dp_l; (void)two53; (void)L1; (void)L2; (void)L3; (void)L4; (void)L5; (void)L6; (void)cp; (void)cp_h;
+    (void)cp_l; (void)ivln2; (void)ivln2_h; (void)ivln2_l;
+    y1 = jm_set_lo(y, 0);
+    p_l = (y - y1) * t1 + y * t2;
+    p_h = y1 * t1;
+    z = p_l + p_h;
+    j = jm_hi(z);
+    i = (int32_t)jm_lo(z);
+    if (j >= 0x40900000) {
+        if (((j - 0x40900000) | i) != 0) return s * huge * huge;
+        if (p_l + ovt > z - p_h) return s * huge * huge;
+    } else if ((j & 0x7fffffff) >= 0x4090cc00) {
+        if (((j - (int32_t)0xc090cc00) | i) != 0) return s * tiny * tiny;
+        if (p_l <= z - p_h) return s * tiny * tiny;
+    }
+    i = j & 0x7fffffff;
+    k = (i >> 20) - 0x3ff;
+    n = 0;
+    if (i > 0x3fe00000) {
+        n = j + (0x00100000 >> (k + 1));
+        k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+        t = jm_words(n & ~(0x000fffff >> k), 0);
+        n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+        if (j < 0) n = -n;
+        p_h -= t;
+    }
+    t = jm_set_lo(p_l + p_h, 0);
+    u = t * lg2_h;
+    v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+    z = u + v;
+    w = v - (z - u);
+    t = z * z;
+    t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    r = (z * t1) / (t1 - 2.0) - (w + z * w);
+    z = 1.0 - (r - z);
+    j = jm_hi(z);
+    j += (int32_t)((uint32_t)n << 20);
+    if ((j >> 20) <= 0) z = __builtin_ldexp(z, n);
+    else z = jm_set_hi(z, j);
+    return s * z;
+}
+
+__device__ inline bool jm_pow_ordinary_exponent(double y) {
+    const int32_t hy = jm_hi(y), iy = hy & 0x7fffffff;
+    const uint32_t ly = jm_lo(y);
+    if ((iy | (int32_t)ly) == 0 || iy >= 0x7ff00000 || iy > 0x41e00000) return false;
+    if (ly == 0 && (iy == 0x3ff00000 || hy == 0x40000000 || hy == 0x3fe00000)) return false;
+    return true;
+}
+
+/* ra = Math.pow(x, ya), rb = Math.pow(x, yb) */
+__device__ inline void js_pow_pair(double x, double ya, double yb, double &ra, double &rb) {
+    const int32_t hx = jm_hi(x), ix = hx & 0x7fffffff;
+    const bool base_ok = hx > 0 && ix < 0x7ff00000 && !(jm_lo(x) == 0 && ix == 0x3ff00000);
+    if (base_ok && jm_pow_ordinary_exponent(ya) && jm_pow_ordinary_exponent(yb)) {
+        double t1, t2;
+        jm_pow_log2(x, ix, t1, t2);
+        ra = jm_pow_exp2(ya, t1, t2);
+        rb = jm_pow_exp2(yb, t1, t2);
+        return;
+    }
+    ra = js_pow(x, ya);
+    rb = js_pow(x, yb);
+}
+
+/* Math.sin(x) and Math.cos(x) with one argument reduction (same kernels, same values) */
+__device__ inline void js_sincos(double x, double &sn, double &cs) {
+    int32_t ix = jm_hi(x) & 0x7fffffff;
+    if (ix <= 0x3fe921fb) {
+        sn = jm_ksin(x, 0.0, 0);
+        cs = jm_kcos(x, 0.0);
+        return;
+    }
+    if (ix >= 0x7ff00000) {
+        sn = cs = x - x;
+        return;
+    }
+    double y[2]; int ok; int n = jm_rem_pio2(x, y, &ok);
+    if (!ok) {
+        sn = cs = __builtin_nan("");
+        return;
+    }
+    const double ks = jm_ksin(y[0], y[1], 1), kc = jm_kcos(y[0], y[1]);
+    switch (n & 3) {
+        case 0: sn = ks; cs = kc; break;
+        case 1: sn = kc; cs = -ks; break;
+        case 2: sn = -ks; cs = -kc; break;
+        default: sn = -kc; cs = ks; break;
+    }
+}
+
 /* Math.round: __builtin_floor(x + 0.5) with the ties and signed-zero rules of ECMA-262 21.3.2.28 */
 __device__ inline double js_round(double x) {
     if (!(__builtin_fabs(x) < 4503599627370496.0)) return x; /* NaN, inf and integers beyond 2^52 */

@@ -57,14 +57,18 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
         double theta = js_atan2(z1, z0);
         double phi = js_asin(static_cast<double>(z2) / r);
         if (animate) phi += time * speed;
-        dr = js_pow(r, power - 1.0) * dr * power + 1.0;
-        r = js_pow(r, power);
+        double pw_m1, pw;  // Math.pow(r, power - 1), Math.pow(r, power): one log2(r) for both
+        js_pow_pair(r, power - 1.0, power, pw_m1, pw);
+        dr = pw_m1 * dr * power + 1.0;
+        r = pw;
         theta = theta * power;
         phi = phi * power;
-        const double cphi = js_cos(phi);
-        z0 = to_f32(r * js_cos(theta) * cphi + static_cast<double>(p0));
-        z1 = to_f32(r * js_sin(theta) * cphi + static_cast<double>(p1));
-        z2 = to_f32(r * js_sin(phi) + static_cast<double>(p2));
+        double sth, cth, sph, cph;  // one argument reduction per angle
+        js_sincos(theta, sth, cth);
+        js_sincos(phi, sph, cph);
+        z0 = to_f32(r * cth * cph + static_cast<double>(p0));
+        z1 = to_f32(r * sth * cph + static_cast<double>(p1));
+        z2 = to_f32(r * sph + static_cast<double>(p2));
     }
     return 0.5 * js_log(r) * r / dr;
 }
@@ -134,7 +138,8 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
             transform_mat4(I.Tinv, ((I.flags >> 1) & 1) | ((I.flags >> 3) & 1) << 2, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
             if (op == 13) {  // twist.ts:21-33
                 const double a = I.p[0] * static_cast<double>(wy);
-                const double c = js_cos(a), s = js_sin(a);
+                double c, s;
+                js_sincos(a, s, c);
                 const float tx = to_f32(c * static_cast<double>(wx) - s * static_cast<double>(wz));
                 const float tz = to_f32(s * static_cast<double>(wx) + c * static_cast<double>(wz));
                 wx = tx;

@@ -9,8 +9,8 @@
  * its published algorithms are restated here (double arithmetic, one rounding per operation:
  * compile with -ffp-contract=off) and pinned by comparing bit patterns with the Math.* of the
  * node binary in the build container (tests/test_oracle_kat.py::test_jsmath_equals_node).
- * Argument reduction covers |x| <= 2^19*pi/2 (the "medium" path of e_rem_pio2.c); larger
- * arguments cannot occur for points within MAX_DIST of the camera and return NaN.
+ * Argument reduction is complete: the "medium" path of e_rem_pio2.c up to 2^19*pi/2 and the
+ * Payne-Hanek path of k_rem_pio2.c beyond.
  */
 #ifndef RO_JSMATH_H
 #define RO_JSMATH_H
@@ -56,7 +56,124 @@ static inline double jm_kcos(double x, double y) {
     return a - (hz - (z * r - x * y));
 }
 
-/* e_rem_pio2.c, |x| <= 2^19*pi/2; returns n, y[0]+y[1] = x - n*pi/2.  *ok = 0 beyond that. */
+/* k_rem_pio2.c: Payne-Hanek reduction for |x| > 2^19*pi/2.  x[0..nx) are 24-bit pieces of |x| scaled by
+ * 2^-e0; ipio2 holds 2/pi in 24-bit pieces (1584 bits, generated from pi with integer arithmetic and
+ * equal to the published table).  prec = 2 (double): jk = 4. */
+static inline int jm_kernel_rem_pio2(const double *x, double *y, int e0, int nx) {
+    static const int32_t ipio2[66] = {
+        0xA2F983, 0x6E4E44, 0x1529FC, 0x2757D1, 0xF534DD, 0xC0DB62, 0x95993C, 0x439041,
+        0xFE5163, 0xABDEBB, 0xC561B7, 0x246E3A, 0x424DD2, 0xE00649, 0x2EEA09, 0xD1921C,
+        0xFE1DEB, 0x1CB129, 0xA73EE8, 0x8235F5, 0x2EBB44, 0x84E99C, 0x7026B4, 0x5F7E41,
+        0x3991D6, 0x398353, 0x39F49C, 0x845F8B, 0xBDF928, 0x3B1FF8, 0x97FFDE, 0x05980F,
+        0xEF2F11, 0x8B5A0A, 0x6D1F6D, 0x367ECF, 0x27CB09, 0xB74F46, 0x3F669E, 0x5FEA2D,
+        0x7527BA, 0xC7EBE5, 0xF17B3D, 0x0739F7, 0x8A5292, 0xEA6BFB, 0x5FB11F, 0x8D5D08,
+        0x560330, 0x46FC7B, 0x6BABF0, 0xCFBC20, 0x9AF436, 0x1DA9E3, 0x91615E, 0xE61B08,
+        0x659985, 0x5F14A0, 0x68408D, 0xFFD880, 0x4D7327, 0x310606, 0x1556CA, 0x73A8C9,
+        0x60E27B, 0xC08C6B};
+    static const double PIo2[8] = {1.57079625129699707031e+00, 7.54978941586159635335e-08, 5.39030252995776476554e-15,
+                                   3.28200341580791294123e-22, 1.27065575308067607349e-29, 1.22933308981111328932e-36,
+                                   2.73370053816464559624e-44, 2.16741683877804819444e-51};
+    const double two24 = 1.67772160000000000000e+07, twon24 = 5.96046447753906250000e-08;
+    int32_t jz, jx, jv, jp, jk, carry, n, iq[20], i, j, k, m, q0, ih;
+    double z, fw, f[20], fq[20], q[20];
+    jk = 4;
+    jp = jk;
+    jx = nx - 1;
+    jv = (e0 - 3) / 24;
+    if (jv < 0) jv = 0;
+    q0 = e0 - 24 * (jv + 1);
+    j = jv - jx;
+    m = jx + jk;
+    for (i = 0; i <= m; i++, j++) f[i] = (j < 0) ? 0.0 : (double)ipio2[j];
+    for (i = 0; i <= jk; i++) {
+        for (j = 0, fw = 0.0; j <= jx; j++) fw += x[j] * f[jx + i - j];
+        q[i] = fw;
+    }
+    jz = jk;
+    for (;;) {  /* recompute: */
+        for (i = 0, j = jz, z = q[jz]; j > 0; i++, j--) {
+            fw = (double)((int32_t)(twon24 * z));
+            iq[i] = (int32_t)(z - two24 * fw);
+            z = q[j - 1] + fw;
+        }
+        z = scalbn(z, q0);
+        z -= 8.0 * floor(z * 0.125);
+        n = (int32_t)z;
+        z -= (double)n;
+        ih = 0;
+        if (q0 > 0) {
+            i = (iq[jz - 1] >> (24 - q0));
+            n += i;
+            iq[jz - 1] -= i << (24 - q0);
+            ih = iq[jz - 1] >> (23 - q0);
+        } else if (q0 == 0) ih = iq[jz - 1] >> 23;
+        else if (z >= 0.5) ih = 2;
+        if (ih > 0) {
+            n += 1;
+            carry = 0;
+            for (i = 0; i < jz; i++) {
+                j = iq[i];
+                if (carry == 0) {
+                    if (j != 0) { carry = 1; iq[i] = 0x1000000 - j; }
+                } else iq[i] = 0xffffff - j;
+            }
+            if (q0 > 0) {
+                switch (q0) {
+                case 1: iq[jz - 1] &= 0x7fffff; break;
+                case 2: iq[jz - 1] &= 0x3fffff; break;
+                }
+            }
+            if (ih == 2) {
+                z = 1.0 - z;
+                if (carry != 0) z -= scalbn(1.0, q0);
+            }
+        }
+        if (z == 0.0) {
+            j = 0;
+            for (i = jz - 1; i >= jk; i--) j |= iq[i];
+            if (j == 0) { /* need recomputation */
+                for (k = 1; iq[jk - k] == 0; k++) {}
+                for (i = jz + 1; i <= jz + k; i++) {
+                    f[jx + i] = (double)ipio2[jv + i];
+                    for (j = 0, fw = 0.0; j <= jx; j++) fw += x[j] * f[jx + i - j];
+                    q[i] = fw;
+                }
+                jz += k;
+                continue;
+            }
+        }
+        break;
+    }
+    if (z == 0.0) {
+        jz -= 1;
+        q0 -= 24;
+        while (iq[jz] == 0) { jz--; q0 -= 24; }
+    } else {
+        z = scalbn(z, -q0);
+        if (z >= two24) {
+            fw = (double)((int32_t)(twon24 * z));
+            iq[jz] = (int32_t)(z - two24 * fw);
+            jz += 1;
+            q0 += 24;
+            iq[jz] = (int32_t)fw;
+        } else iq[jz] = (int32_t)z;
+    }
+    fw = scalbn(1.0, q0);
+    for (i = jz; i >= 0; i--) { q[i] = fw * (double)iq[i]; fw *= twon24; }
+    for (i = jz; i >= 0; i--) {
+        for (fw = 0.0, k = 0; k <= jp && k <= jz - i; k++) fw += PIo2[k] * q[i + k];
+        fq[jz - i] = fw;
+    }
+    fw = 0.0;
+    for (i = jz; i >= 0; i--) fw += fq[i];
+    y[0] = (ih == 0) ? fw : -fw;
+    fw = fq[0] - fw;
+    for (i = 1; i <= jz; i++) fw += fq[i];
+    y[1] = (ih == 0) ? fw : -fw;
+    return n & 7;
+}
+
+/* e_rem_pio2.c; returns n, y[0]+y[1] = x - n*pi/2 (*ok is always 1 since the large path exists) */
 static inline int jm_rem_pio2(double x, double *y, int *ok) {
     static const int32_t npio2_hw[32] = {
         0x3FF921FB, 0x400921FB, 0x4012D97C, 0x401921FB, 0x401F6A7A, 0x4022D97C, 0x4025FDBB, 0x402921FB,
@@ -104,9 +221,22 @@ static inline int jm_rem_pio2(double x, double *y, int *ok) {
         if (hx < 0) { y[0] = -y[0]; y[1] = -y[1]; return -n; }
         return n;
     }
-    *ok = 0;
-    y[0] = y[1] = NAN;
-    return 0;
+    if (ix >= 0x7ff00000) { y[0] = y[1] = x - x; return 0; }
+    {   /* set z = scalbn(|x|, ilogb(x) - 23), split it into three 24-bit pieces */
+        const int e0 = (ix >> 20) - 1046;
+        double z = jm_words(ix - (int32_t)((uint32_t)e0 << 20), jm_lo(x));
+        double tx[3];
+        for (int i = 0; i < 2; i++) {
+            tx[i] = (double)((int32_t)z);
+            z = (z - tx[i]) * 1.67772160000000000000e+07;
+        }
+        tx[2] = z;
+        int nx = 3;
+        while (tx[nx - 1] == 0.0) nx--;
+        const int n = jm_kernel_rem_pio2(tx, y, e0, nx);
+        if (hx < 0) { y[0] = -y[0]; y[1] = -y[1]; return -n; }
+        return n;
+    }
 }
 
 static inline double js_sin(double x) {

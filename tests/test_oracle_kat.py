@@ -186,8 +186,11 @@ def _jsmath(oracle, fn, a, b=None):
 
 
 def _jsmath_inputs(rng, n):
-    trig = np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-8e5, 8e5, n // 4), rng.normal(0, 1e-3, n // 8),
-                           (np.arange(n // 8) - n // 16) * np.pi / 2 * (1 + rng.normal(0, 1e-9, n // 8))])
+    trig = np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-8e5, 8e5, n // 8), rng.normal(0, 1e-3, n // 8),
+                           (np.arange(n // 8) - n // 16) * np.pi / 2 * (1 + rng.normal(0, 1e-9, n // 8)),
+                           # beyond 2^19*pi/2: the Payne-Hanek reduction of k_rem_pio2.c
+                           rng.uniform(8e5, 1e7, n // 32), 10.0 ** rng.uniform(6, 300, n // 16) * rng.choice([-1, 1], n // 16),
+                           2.0 ** rng.integers(20, 1023, n // 32).astype(float)])
     y = rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 5, n)
     x = rng.normal(0, 1, n) * 10.0 ** rng.integers(-5, 5, n)
     unit = np.concatenate([rng.uniform(-1, 1, n - 1000), 1 - 10.0 ** rng.uniform(-16, 0, 1000)])

@@ -41,8 +41,9 @@ typedef struct rm_ctx rm_ctx;
 typedef enum rm_status {
     RM_OK = 0,
     RM_E_INVALID = -1,     /* null pointer, negative size, non-finite camera ...            */
-    RM_E_UNSUPPORTED = -2, /* preset with non-sphere primitives or SDF operators (the host  */
-                           /* keeps its own CPU path for those jobs)                        */
+    RM_E_UNSUPPORTED = -2, /* valid request the native path cannot serve (operator tree     */
+                           /* nested deeper than 15, BVH leaf above 255 primitives): the    */
+                           /* host keeps its own CPU path for that job                      */
     RM_E_NO_DEVICE = -3,   /* ctx was created host-only, or no HIP device                   */
     RM_E_HIP = -4,         /* a HIP runtime call failed; rm_last_error has the text         */
     RM_E_NO_SCENE = -5,    /* render requested before any scene was set                     */

@@ -92,6 +92,35 @@ def cpu_baseline(wl, budget_s=20.0):
             "sample_avg_sdf_calls_per_pixel": total / (len(rows) * W)}
 
 
+def js_engine_baseline(wl, rows=32):
+    """The JS restatement (oracle/rm_oracle.js) on this host's node, one thread, on a band of `rows`
+    rows in the middle of the frame: what the reference's own language runtime does per worker.
+    Returns None when node is absent or the workload has no JS description (synthetic scenes)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("node") is None or "preset" not in wl:
+        return None
+    W, H = wl["width"], wl["height"]
+    y0 = H // 2 - rows // 2
+    cfg = dict(preset=wl["preset"], accel=wl["accel"], width=W, height=H, shader=wl["shader"], yStart=y0, yEnd=y0 + rows)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "cfg.json"), "w") as f:
+            json.dump(cfg, f)
+        try:
+            out = subprocess.check_output(["node", os.path.join(ROOT, "oracle", "rm_oracle.js"), "render",
+                                           os.path.join(td, "cfg.json"), os.path.join(td, "out")], timeout=120)
+            st = json.loads(out)
+        except Exception:
+            return None
+    ms = st.get("render_ms")
+    if not ms:
+        return None
+    return {"value": 1.0 / (ms * 1e-3 * H / rows), "unit": "frames/s", "threads": 1, "engine": st.get("engine"),
+            "sample": "rows [%d,%d) of the %dx%d frame in %.0f ms, scaled by H/rows; the reference runs "
+                      "min(4, cores-1) such workers (main.ts:318)" % (y0, y0 + rows, W, H, ms)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,6 +379,9 @@ def main():
                  "frame_ms": e0.elapsed_time(e1)} for (y, a), (e0, e1) in zip(series, ev_pairs)]
         if world == 1 and not args.no_cpu_baseline and not args.analytics_sweep:
             out["cpu_baseline"] = cpu_baseline(wl)
+            js = js_engine_baseline(wl)
+            if js:
+                out["cpu_baseline"]["js_engine_single_thread"] = js
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -311,13 +311,25 @@ struct Interval {
 // intersectRayBox (octree.ts:195-220) has no zero-direction guard and stores t0/t1 in a
 // Float32Array; 0 * Infinity = NaN then flows through Math.max/min (NaN-propagating) and
 // every comparison with NaN is false.
-__device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, double t) {
+// 1 / direction[i] as intersectRayBox computes it for every call (octree.ts:200; no zero guard: +-Infinity for a
+// zero component): the same three quotients for every node of a ray, so the marchers compute them once.
+struct OctInv {
+    double inv[3];
+};
+__device__ __forceinline__ OctInv make_oct_inv(const Ray &r) {
+    OctInv o;
+    o.inv[0] = 1.0 / static_cast<double>(r.d.x);
+    o.inv[1] = 1.0 / static_cast<double>(r.d.y);
+    o.inv[2] = 1.0 / static_cast<double>(r.d.z);
+    return o;
+}
+
+__device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, double t, const OctInv &oi) {
     if (!nd.is_empty) return 0.0;
-    const float d[3] = {r.d.x, r.d.y, r.d.z};
     float tn[3], tf[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const double inv = 1.0 / static_cast<double>(d[a]);
+        const double inv = oi.inv[a];
         double t0 = (static_cast<double>(nd.lo[a]) - r.od[a]) * inv;
         double t1 = (static_cast<double>(nd.hi[a]) - r.od[a]) * inv;
         if (inv < 0.0) {
@@ -347,6 +359,9 @@ __device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, do
     double step = toExit < cap ? toExit : cap;
     step = step > 0.0 ? step : 0.0;
     return step > 0.0 ? step + 0.001 : 0.0;
+}
+__device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, double t) {
+    return oct_skip(nd, r, t, make_oct_inv(r));
 }
 
 // ------------------------------------------------------------------ ray generation / stores

@@ -253,6 +253,8 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
     Interval cur;
     bool haveCur = false;
     RayInv ri;
+    OctInv oinv;
+    if (ACCEL == 1) oinv = make_oct_inv(ray);
     if (ACCEL == 2) {
         ri = make_ray_inv(ray);
         haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);  // onRayMarchStart
@@ -283,7 +285,7 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
         } else if (ACCEL == 1) {
             onode = oct_find(P, p);  // marchRay recomputes this same point
             if (onode >= 0) {
-                const double skip = oct_skip(P.oct[onode], ray, t);
+                const double skip = oct_skip(P.oct[onode], ray, t, oinv);
                 if (skip > 0.0) {
                     t += skip;
                     if (t > RM_MAX_DIST) break;
@@ -320,6 +322,8 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     Interval cur;
     bool haveCur = false;
     RayInv ri;
+    OctInv oinv;
+    if (ACCEL == 1) oinv = make_oct_inv(ray);
     if (ACCEL == 2) {
         ri = make_ray_inv(ray);
         haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);
@@ -340,7 +344,7 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
             }
         } else if (ACCEL == 1) {
             onode = oct_find(P, p);
-            if (onode >= 0) skip = oct_skip(P.oct[onode], ray, t);
+            if (onode >= 0) skip = oct_skip(P.oct[onode], ray, t, oinv);
         }
         if (skip > 0.0) {
             t += skip;

@@ -95,6 +95,26 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
         assert_same(outs[0], cpu_render(oracle, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres), "vs oracle")
 
 
+@pytest.mark.parametrize("n,seed", [(30, 1), (120, 2), (300, 3), (500, 4)])
+def test_random_sphere_scenes_with_candidate_lists(rm, oracle, n, seed):
+    """Scenes of <= 512 spheres use the nearest-candidate grid for the all-primitive fallback: random
+    centres and very unequal radii (the candidate bound involves the radius) against the oracle,
+    with the lists forced on, forced off and in the v1 kernel."""
+    rng = np.random.default_rng(seed)
+    sp = np.zeros((n, 4))
+    sp[:, :3] = rng.uniform(-1.4, 1.4, (n, 3)).astype(np.float32)
+    sp[:, 3] = rng.choice([0.02, 0.05, 0.12, 0.3, 0.5], n) * rng.uniform(0.8, 1.2, n)
+    ctx = rm.Context(0)
+    want = cpu_render(oracle, None, "BVH", 240, 150, (0.35, -0.8), spheres=sp)
+    for opts in (dict(kernel=2, nn=1), dict(kernel=2, nn=0), dict(kernel=2, nn=1, coop=0, filter=0), dict(kernel=1)):
+        for k, v in dict(kernel=0, nn=2, coop=1, filter=1).items():
+            ctx.set_option(k, v)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        assert_same(gpu_render(rm, ctx, None, "BVH", 240, 150, (0.35, -0.8), spheres=sp), want, "n=%d %s" % (n, opts))
+    ctx.close()
+
+
 @pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
 def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):

@@ -221,6 +221,8 @@ void fill_scene_repr(const rm_ctx *ctx, RmRenderParams &p) {
     p.prims = ctx->dev.prims;
     p.prog = ctx->dev.prog;
     p.obj_ranges = ctx->dev.obj_ranges;
+    p.prog_slots = ctx->host.prog_slots;
+    p.prog_vals = ctx->host.prog_vals;
 }
 
 int clamp_preset(int idx) { return idx < 0 ? 0 : (idx > rmh::kPresetCount - 1 ? rmh::kPresetCount - 1 : idx); }

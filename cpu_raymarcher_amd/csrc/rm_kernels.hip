@@ -39,7 +39,8 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
     if (GEN >= 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
         for (int k = 0; k < n; ++k) {
             const int obj = ids ? ids[k] : k;
-            closest = js_min_nan(program_sdf<GEN == 3>(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time), closest);
+            closest = js_min_nan(program_sdf<GEN == 3>(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time, P.prog_slots),
+                                 closest);
         }
         return closest;
     }
@@ -638,7 +639,9 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
-#define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, 0, stream, p)
+    // expression programs keep their position slots and pending values in LDS (rm_program.h)
+    const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+#define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, shmem, stream, p)
 #define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G); else if (p.accel == 1) RM_V1(1, O, G); else RM_V1(0, O, G); }
     if (p.general == 3) {
         if (p.algorithm == 0) RM_V1A(false, 3) else RM_V1A(true, 3)
@@ -683,7 +686,8 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
                               hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
-#define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, 0, stream, p, points, n, dist, count)
+    const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+#define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, shmem, stream, p, points, n, dist, count)
     if (p.general == 3) { if (p.accel == 2) RM_DK(2, 3); else if (p.accel == 1) RM_DK(1, 3); else RM_DK(0, 3); }
     else if (p.general == 2) { if (p.accel == 2) RM_DK(2, 2); else if (p.accel == 1) RM_DK(1, 2); else RM_DK(0, 2); }
     else if (p.general) { if (p.accel == 2) RM_DK(2, 1); else if (p.accel == 1) RM_DK(1, 1); else RM_DK(0, 1); }

@@ -7,6 +7,12 @@
 #include "rm_device.h"
 #include "rm_jsmath.h"
 
+// Position slots and pending values of the interpreter live in LDS (dynamic shared memory of the launch,
+// sized by the host from the scene's deepest program): slot s, component c of thread t is word
+// (s*3 + c) * blockDim + t, so a wave's access is one conflict-free row.  Private arrays indexed by the
+// (uniform, but run-time) slot number had gone to scratch: three vector-memory round trips per instruction.
+extern __shared__ __align__(16) unsigned char rm_prog_smem[];
+
 namespace rmd {
 
 // Math.min / Math.max: NaN if either argument is NaN (the Mandelbulb can produce NaN at its pole)
@@ -77,35 +83,40 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
 // code doubles the register need (200 against 106 VGPRs), so scenes without one get an instantiation that runs
 // four waves per SIMD instead of two.
 template <bool MB>
-__device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time) {
-    float px[RM_PROG_MAX_SLOTS], py[RM_PROG_MAX_SLOTS], pz[RM_PROG_MAX_SLOTS];
-    double val[RM_PROG_MAX_VALS];
+__device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time,
+                                                        int n_slots) {
+    const int nt = blockDim.x, tid = threadIdx.x;
+    float *pos = reinterpret_cast<float *>(rm_prog_smem) + tid;                              // [(s*3 + c) * nt]
+    double *val = reinterpret_cast<double *>(rm_prog_smem + static_cast<size_t>(n_slots) * 3 * nt * 4) + tid;  // [k * nt]
     int sp = 0;
-    px[0] = p.x;
-    py[0] = p.y;
-    pz[0] = p.z;
+    pos[0] = p.x;
+    pos[nt] = p.y;
+    pos[2 * nt] = p.z;
     for (int pc = first; pc < first + count; ++pc) {
         const RmInstr &I = prog[pc];
         const int op = I.op;
         if (op >= 20) {  // POST
             if (op == 20) {  // round.ts:24
-                val[sp - 1] = val[sp - 1] - I.p[0];
+                val[(sp - 1) * nt] = val[(sp - 1) * nt] - I.p[0];
             } else {
-                const double d1 = val[sp - 2], d2 = val[sp - 1];
+                const double d1 = val[(sp - 2) * nt], d2 = val[(sp - 1) * nt];
                 const double k = I.p[0] * 4.0;
                 sp -= 1;
                 if (op == 21) {  // smoothUnion.ts:31-34
                     const double h = js_max_nan(k - __builtin_fabs(d1 - d2), 0.0);
-                    val[sp - 1] = js_min_nan(d1, d2) - h * h * 0.25 / k;
+                    val[(sp - 1) * nt] = js_min_nan(d1, d2) - h * h * 0.25 / k;
                 } else {  // smoothSubstraction.ts:30-33
                     const double h = js_max_nan(k - __builtin_fabs(d1 + d2), 0.0);
-                    val[sp - 1] = js_max_nan(d1, -d2) + h * h * 0.25 / k;
+                    val[(sp - 1) * nt] = js_max_nan(d1, -d2) + h * h * 0.25 / k;
                 }
             }
             continue;
         }
         float lx, ly, lz;
-        transform_mat4(I.T, (I.flags & 1) | ((I.flags >> 2) & 1) << 2, px[I.src], py[I.src], pz[I.src], lx, ly, lz);  // primitive.ts:34-35
+        {
+            const float *src = pos + I.src * 3 * nt;
+            transform_mat4(I.T, (I.flags & 1) | ((I.flags >> 2) & 1) << 2, src[0], src[nt], src[2 * nt], lx, ly, lz);  // primitive.ts:34-35
+        }
         if (op < 10) {  // leaves
             double d;
             if (op == 1) {  // box.ts:13-30
@@ -124,7 +135,8 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
             } else {  // sphere.ts:12-14
                 d = hypot3_shared_rcp(lx, ly, lz) - I.p[0];
             }
-            val[sp++] = d;
+            val[sp * nt] = d;
+            sp += 1;
             continue;
         }
         // PRE: the point the operands see
@@ -150,9 +162,10 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
                 wz = to_f32(static_cast<double>(wz) - I.p[2] * js_round(static_cast<double>(wz) / I.p[2]));
             }
         }
-        px[I.dst] = wx;
-        py[I.dst] = wy;
-        pz[I.dst] = wz;
+        float *dst = pos + I.dst * 3 * nt;
+        dst[0] = wx;
+        dst[nt] = wy;
+        dst[2 * nt] = wz;
     }
     return val[0];
 }

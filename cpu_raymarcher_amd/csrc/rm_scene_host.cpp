@@ -799,7 +799,9 @@ struct Forest {
         }
     }
     // post-order instruction stream of the subtree rooted at i, reading its point from slot `slot`
+    mutable int max_slot = 0, max_vals = 0;
     bool compile(int i, int slot, int &depth_vals, std::vector<RmInstr> &out, std::string &err) const {
+        max_slot = std::max(max_slot, slot);
         if (slot + 1 >= RM_PROG_MAX_SLOTS) {
             err = "expression tree deeper than RM_PROG_MAX_SLOTS";
             return false;
@@ -825,6 +827,7 @@ struct Forest {
         ins.dst = slot + 1;
         if (d.type < 10) {
             out.push_back(ins);
+            max_vals = std::max(max_vals, depth_vals + 1);
             if (++depth_vals > RM_PROG_MAX_VALS) {
                 err = "expression needs more than RM_PROG_MAX_VALS pending values";
                 return false;
@@ -1023,6 +1026,12 @@ bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const i
             s.prim_lo[3 * r + k] = to_f32(double(wp[k]) - pad);
             s.prim_hi[3 * r + k] = to_f32(double(wp[k]) + pad);
         }
+    }
+    s.prog_slots = f.max_slot + 1;
+    s.prog_vals = std::max(1, f.max_vals);
+    if ((size_t(s.prog_slots) * 12 + size_t(s.prog_vals) * 8) * 256 > 64 * 1024) {
+        err = "expression forest exceeds the interpreter's LDS budget (RM_PROG_MAX_SLOTS / RM_PROG_MAX_VALS)";
+        return false;
     }
     return build_accel(s, n_roots, err);
 }

@@ -34,6 +34,7 @@ struct HostScene {
     int preset = 0;
     bool general = false;         // RmPrim records instead of RmSphere
     bool program = false;         // expression programs (RmInstr) instead of either
+    int prog_slots = 1, prog_vals = 1;  // what the deepest program needs (device LDS sizing)
     std::vector<RmInstr> prog;
     std::vector<int32_t> obj_ranges;  // (first, count) per scene object
     std::vector<RmPrim> prims;

@@ -142,6 +142,7 @@ struct RmRenderParams {
     const RmPrim *prims;
     const RmInstr *prog;         // general == 2: instructions of every scene object, concatenated
     const int32_t *obj_ranges;   // general == 2: (first, count) into prog per scene object
+    int32_t prog_slots, prog_vals;  // general >= 2: position slots / pending values of the deepest program (LDS sizing)
     double time;                 // Scene.updateTime(time) (raymarcher.ts:58-59): animated primitives
     double overshoot;    // AdaptiveStepV2/V3 overshootFactor (default 1.2)
     double step_size;    // FixedStep stepSize (default 0.1)

@@ -49,6 +49,14 @@ __device__ __forceinline__ void transform_mat4(const float *m, int flags, float 
     oz = to_f32((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
 }
 
+// Out-of-line copies for the Mandelbulb's escape loop: inlined, the five fdlibm bodies push the kernel to 226
+// VGPRs (2 waves/SIMD); as calls the register need is the largest callee's, not their sum.
+__device__ __attribute__((noinline)) double mb_atan2(double y, double x) { return js_atan2(y, x); }
+__device__ __attribute__((noinline)) double mb_asin(double x) { return js_asin(x); }
+__device__ __attribute__((noinline)) double mb_log(double x) { return js_log(x); }
+__device__ __attribute__((noinline)) void mb_pow_pair(double x, double ya, double yb, double &ra, double &rb) { js_pow_pair(x, ya, yb, ra, rb); }
+__device__ __attribute__((noinline)) void mb_sincos(double x, double &s, double &c) { js_sincos(x, s, c); }
+
 // mandelbulb.ts:37-78; z is a Float32Array: each component store rounds to binary32
 __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, float lz, double time) {
     const double power = prm[0], speed = prm[3];
@@ -60,23 +68,23 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
     for (int i = 0; i < iterations; ++i) {
         r = hypot3_shared_rcp(z0, z1, z2);
         if (r > 2.0) break;
-        double theta = js_atan2(z1, z0);
-        double phi = js_asin(static_cast<double>(z2) / r);
+        double theta = mb_atan2(z1, z0);
+        double phi = mb_asin(static_cast<double>(z2) / r);
         if (animate) phi += time * speed;
         double pw_m1, pw;  // Math.pow(r, power - 1), Math.pow(r, power): one log2(r) for both
-        js_pow_pair(r, power - 1.0, power, pw_m1, pw);
+        mb_pow_pair(r, power - 1.0, power, pw_m1, pw);
         dr = pw_m1 * dr * power + 1.0;
         r = pw;
         theta = theta * power;
         phi = phi * power;
         double sth, cth, sph, cph;  // one argument reduction per angle
-        js_sincos(theta, sth, cth);
-        js_sincos(phi, sph, cph);
+        mb_sincos(theta, sth, cth);
+        mb_sincos(phi, sph, cph);
         z0 = to_f32(r * cth * cph + static_cast<double>(p0));
         z1 = to_f32(r * sth * cph + static_cast<double>(p1));
         z2 = to_f32(r * sph + static_cast<double>(p2));
     }
-    return 0.5 * js_log(r) * r / dr;
+    return 0.5 * mb_log(r) * r / dr;
 }
 
 // One scene object: returns Primitive.sdf(p) of the root node.  MB = the scene has a Mandelbulb leaf: its fdlibm

@@ -85,12 +85,17 @@ class ShardedFrameRenderer:
     sections of `packed` starting at tile-local row `local_row` (on the GPU: one
     rm_render_tile_device launch per range; the CPU gloo test injects the oracle)."""
 
-    def __init__(self, layout, rank, world, render_rows, new_buffer, dist=None, double_buffer=True, render_all=None):
+    def __init__(self, layout, rank, world, render_rows, new_buffer, dist=None, double_buffer=True, render_all=None,
+                 frames_in_flight=None, streams=None):
+        """frames_in_flight: buffer sets (default 2 = double buffering).  streams: one device stream per buffer
+        set; frame n is rendered, gathered and assembled on stream n % frames_in_flight, so the tail of one
+        frame's persistent kernel overlaps the start of the next (None: everything on the current stream)."""
         self.layout, self.rank, self.world = layout, rank, world
         self.render_rows = render_rows
         self.render_all = render_all  # optional: one call that fills every owned row of `packed`
         self.dist = dist
-        self.nbuf = 2 if double_buffer else 1
+        self.nbuf = int(frames_in_flight) if frames_in_flight else (2 if double_buffer else 1)
+        self.streams = streams
         self.send = [new_buffer(layout.nbytes) for _ in range(self.nbuf)]
         self.recv = [[new_buffer(layout.nbytes) for _ in range(world)] if (rank == 0 and world > 1) else None
                      for _ in range(self.nbuf)]
@@ -106,10 +111,23 @@ class ShardedFrameRenderer:
             self.render_rows(a, b, local, self.send[slot])
             local += b - a
 
+    def on_stream(self, slot):
+        """Context manager: the device stream of buffer set `slot` (a no-op without streams)."""
+        if self.streams is None:
+            import contextlib
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.streams[slot])
+
     def submit(self):
         """Render this rank's rows for the next frame and start its gather; returns the slot."""
         slot = self.step % self.nbuf
         self.step += 1
+        with self.on_stream(slot):
+            self._submit(slot)
+        return slot
+
+    def _submit(self, slot):
         if self.work[slot] is not None:
             self.work[slot].wait()  # the buffer's previous gather has been consumed
             self.work[slot] = None
@@ -117,10 +135,13 @@ class ShardedFrameRenderer:
         if self.world > 1:
             self.work[slot] = self.dist.gather(self.send[slot], self.recv[slot] if self.rank == 0 else None, dst=0,
                                                async_op=True)
-        return slot
 
     def finish(self, slot, frame=None):
         """Wait for the gather of `slot`; on rank 0 optionally assemble the full frame."""
+        with self.on_stream(slot):
+            self._finish(slot, frame)
+
+    def _finish(self, slot, frame=None):
         if self.work[slot] is not None:
             self.work[slot].wait()
             self.work[slot] = None
@@ -197,8 +218,10 @@ class GpuFrameAssembler:
                 loc += b - a
         self.rank_of_row, self.local_of_row = rank_of_row.to(device), local_of_row.to(device)
         self.recv2d = [torch.zeros(layout.world, layout.nbytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        self.frame = {s: torch.zeros(SECTION_BYTES[s] * W * H, dtype=torch.uint8, device=device)
-                      for s in layout.sections}
+        # one output frame per buffer set: frames in flight on different streams must not share it
+        self.frames = [{s: torch.zeros(SECTION_BYTES[s] * W * H, dtype=torch.uint8, device=device)
+                        for s in layout.sections} for _ in range(nbuf)]
+        self.frame = self.frames[0]  # the most recently assembled frame
 
     def gather_lists(self):
         """Per slot, the list of per-rank views torch.distributed.gather writes into."""
@@ -211,5 +234,6 @@ class GpuFrameAssembler:
             bpp = SECTION_BYTES[s]
             off = L.offsets[s]
             src = self.recv2d[slot][:, off:off + L.cap * W * bpp].unflatten(1, (L.cap, W * bpp))
-            self.frame[s].view(H, W * bpp).copy_(src[self.rank_of_row, self.local_of_row])
+            self.frames[slot][s].view(H, W * bpp).copy_(src[self.rank_of_row, self.local_of_row])
+        self.frame = self.frames[slot]
         return self.frame

@@ -1,0 +1,52 @@
+"""Do consecutive frames overlap when they are enqueued on alternating HIP streams?  The persistent render
+kernel ends with a tail (the last, slowest rays); a second stream lets the next frame's workgroups take the
+CUs that drain.  Prints ms/frame with 1 stream and with 2 / 3 streams, whole frames and 1/8-row shards.
+usage: python scripts/overlap_probe.py [frames]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import cpu_raymarcher_amd as R
+from cpu_raymarcher_amd import distributed as D
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    W, H = 3840, 2160
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0)
+    scene = R.Scene("BVH", ctx=ctx)
+    scene.loadPreset(3)
+    for world in (1, 8):
+        layout = D.FrameLayout(W, H, world, ("rgba", "sdf", "iters"), "interleaved", 16)
+        render_all = D.gpu_render_all(ctx, scene, W, H, "iteration-heatmap", layout, 0)
+        for nstreams in (1, 2, 3, 4, 6):
+            streams = [torch.cuda.Stream() for _ in range(nstreams)]
+            packed = [torch.zeros(layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+            accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(nstreams)]
+
+            def frame(i):
+                k = i % nstreams
+                with torch.cuda.stream(streams[k]):
+                    render_all(packed[k])
+                    sdf = layout.section(packed[k], "sdf").view(torch.int16)
+                    it = layout.section(packed[k], "iters").view(torch.int16)
+                    ctx.reduce_counters_enqueue(sdf, it, accs[k])
+
+            for i in range(6):
+                frame(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(frames):
+                frame(i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print("1/%d of the rows, %d stream(s): %.3f ms/frame (%.0f frames/s)  acc %s"
+                  % (world, nstreams, 1e3 * dt / frames, frames / dt, accs[0].tolist()[:2]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -20,10 +20,12 @@ def main():
     ctx = R.Context(0)
     scene = R.Scene("BVH", ctx=ctx)
     scene.loadPreset(3)
-    for world in (1, 8):
-        layout = D.FrameLayout(W, H, world, ("rgba", "sdf", "iters"), "interleaved", 16)
+    for world, sections in ((1, ("rgba", "sdf", "iters")), (1, ("depth", "normal", "rgba", "sdf", "iters")),
+                            (1, ("depth", "rgba", "sdf", "iters")), (8, ("rgba", "sdf", "iters"))):
+        layout = D.FrameLayout(W, H, world, sections, "interleaved", 16)
+        print("sections", sections, flush=True)
         render_all = D.gpu_render_all(ctx, scene, W, H, "iteration-heatmap", layout, 0)
-        for nstreams in (1, 2, 3, 4, 6):
+        for nstreams in (1, 4, 6):
             streams = [torch.cuda.Stream() for _ in range(nstreams)]
             packed = [torch.zeros(layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
             accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(nstreams)]

@@ -18,7 +18,7 @@ overlaps the following frames.  Every frame is still rendered, shaded and reduce
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- HBM: 12 B/pixel of mandatory output / render-kernel time (HIP events)
-  cpu_baseline -- the oracle (C restatement, kind "port") on the host cores, rank 0, N = 1
+  cpu_baseline -- the oracle (C restatement, kind "port") on the host cores, rank 0, N = 1 (the only leg that loads oracle/)
 """
 import argparse
 import json
@@ -196,21 +196,12 @@ def main():
         ctx.set_option(k, int(v))
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
-        from oracle.oracle import synthetic_spheres  # scene generator only (SURVEY 8d C5 definition)
+        from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition
         sp = synthetic_spheres(wl["synthetic"])
         scene.loadSpheres(sp[:, :3], sp[:, 3])
     elif "mixed" in wl:
-        from oracle.oracle import synthetic_mixed_prims  # scene generator only
-        triples = []
-        for d in synthetic_mixed_prims(wl["mixed"]):
-            m = R.make_transform(*d["pos"], rotation=d["rot"])  # SceneManager.getTransform
-            if d["type"] == "sphere":
-                triples.append((0, m, [d["r"]]))
-            elif d["type"] == "box":
-                triples.append((1, m, d["half"]))
-            else:
-                triples.append((2, m, [d["radius"], d["radius"] / 4]))  # createTorus: minor = radius / 4
-        scene.loadPrims(triples)
+        from cpu_raymarcher_amd.synthetic import mixed_prims_as_triples, synthetic_mixed_prims
+        scene.loadPrims(mixed_prims_as_triples(synthetic_mixed_prims(wl["mixed"]), R.make_transform))
     else:
         scene.loadPreset(wl["preset"])
     tracer = R.SphereTracer()

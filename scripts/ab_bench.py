@@ -31,7 +31,7 @@ def main():
     ctx = R.Context(0)
     sc = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
-        from oracle.oracle import synthetic_spheres
+        from cpu_raymarcher_amd.synthetic import synthetic_spheres
         sp = synthetic_spheres(wl["synthetic"])
         sc.loadSpheres(sp[:, :3], sp[:, 3])
     else:

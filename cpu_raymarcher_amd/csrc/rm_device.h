@@ -175,6 +175,53 @@ __device__ __forceinline__ double prims_min(const RmSphere *spheres, const doubl
     return closest;
 }
 
+// The same minimum with the exact evaluation taken out of the scan.  Lanes of a wave work on different lists, so a
+// loop that evaluates a sphere exactly as soon as its bound passes executes the FP64 body once per list position
+// at which SOME lane passes.  Here the scan keeps per lane the sphere with the smallest upper bound (k1, hi1, lb1)
+// and the smallest lower bound among the others (lb2); afterwards every lane evaluates its k1 in one common
+// instruction stream.  If lb2 exceeds that exact value no other sphere can be closer (exact_j >= lb_j >= lb2);
+// otherwise (near ties) the list is rescanned with the ordinary filter.  ids == nullptr: spheres base .. base+n-1.
+template <typename IdT>
+__device__ __forceinline__ double prims_min_best(const RmSphere *spheres, const double *radii, const IdT *ids, int n, int base,
+                                                 const Vec3f &p, double closest) {
+    if (n <= 0) return closest;
+    const float inf = __builtin_inff();
+    int k1 = 0;
+    float hi1 = inf, lb1 = inf, lb2 = inf;
+    for (int k = 0; k < n; ++k) {
+        const int id = ids ? static_cast<int>(ids[k]) : base + k;
+        float err;
+        const float a = sphere_sdf_estimate(spheres[id], p, err);
+        const float lb = a - err, hi = a + err;
+        const bool better = hi < hi1;
+        lb2 = __builtin_fminf(lb2, better ? lb1 : lb);
+        k1 = better ? id : k1;
+        lb1 = better ? lb : lb1;
+        hi1 = better ? hi : hi1;
+    }
+    {
+        const double e = sphere_sdf_fast(spheres[k1], radii[k1], p);
+        closest = e < closest ? e : closest;
+    }
+    float ub = f32_upper_bound(closest);
+    if (lb2 <= ub) {
+        for (int k = 0; k < n; ++k) {
+            const int id = ids ? static_cast<int>(ids[k]) : base + k;
+            const RmSphere s = spheres[id];
+            float err;
+            const float a = sphere_sdf_estimate(s, p, err);
+            if (a - err <= ub) {
+                const double e = sphere_sdf_fast(s, radii[id], p);
+                if (e < closest) {
+                    closest = e;
+                    ub = f32_upper_bound(e);
+                }
+            }
+        }
+    }
+    return closest;
+}
+
 // Primitive.sdf (primitive.ts:33-39) with the full vec3.transformMat4 (w = w || 1.0), then
 // Sphere / Box / Torus .localSdf (sphere.ts:12-14, box.ts:13-30, torus.ts:14-25).
 __device__ __forceinline__ double prim_sdf_general(const RmPrim &q, const Vec3f &p) {

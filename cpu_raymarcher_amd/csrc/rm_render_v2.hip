@@ -119,28 +119,7 @@ __device__ __forceinline__ float f32_upper(double v) {
 // exceed the best upper bound so far.  Skipped spheres satisfy exact > best >= result.
 __device__ double lane_min_filtered(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest,
                                     int base = 0) {
-    int k0 = 0;
-    if (closest >= RM_MAX_DIST && n > 0) {  // nothing to compare against yet: the first sphere is evaluated
-        const int id = ids ? ids[0] : base;  // exactly either way (its bound cannot exceed MAX_DIST), skip the estimate
-        const double e = sphere_sdf_fast(S.spheres[id], S.radii[id], p);
-        closest = e < closest ? e : closest;
-        k0 = 1;
-    }
-    float ub = f32_upper(closest);
-    for (int k = k0; k < n; ++k) {
-        const int id = ids ? ids[k] : base + k;
-        const RmSphere s = S.spheres[id];
-        float err;
-        const float a = sphere_sdf_estimate(s, p, err);
-        if (a - err <= ub) {
-            const double e = sphere_sdf_fast(s, S.radii[id], p);
-            if (e < closest) {
-                closest = e;
-                ub = f32_upper(e);
-            }
-        }
-    }
-    return closest;
+    return prims_min_best<int32_t>(S.spheres, S.radii, ids, n, base, p, closest);
 }
 
 __device__ double lane_min_exact(const SceneView &S, const int32_t *ids, int n, const Vec3f &p, double closest, int base = 0) {
@@ -298,7 +277,7 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
         const uint32_t cell = S.nn_cells[(nz * P.nn_dim[1] + ny) * P.nn_dim[0] + nx];  // global memory: ~1 MB of tables
         const int ccnt = static_cast<int>(cell & 0xFFu);
         if (ccnt != 255) {
-            closest = prims_min<true, uint16_t>(S.spheres, S.radii, S.nn_list + (cell >> 8), ccnt, q, RM_MAX_DIST, true);
+            closest = prims_min_best<uint16_t>(S.spheres, S.radii, S.nn_list + (cell >> 8), ccnt, 0, q, RM_MAX_DIST);
             served = true;
         }
     }

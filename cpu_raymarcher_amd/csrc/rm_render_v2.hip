@@ -210,7 +210,7 @@ __device__ double all_prims_wave(const SceneView &S, bool need, const Vec3f &q, 
 }
 
 // BVH branch of Scene.getDistance (scene.ts:167-181); whole wave must call
-__device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
+__device__ double bvh_distance_wave_seq(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
                                     uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
                                     unsigned long long *dbg_fallback_cycles) {
     double closest = RM_MAX_DIST;
@@ -280,6 +280,127 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             closest = prims_min_best<uint16_t>(S.spheres, S.radii, S.nn_list + (cell >> 8), ccnt, 0, q, RM_MAX_DIST);
             served = true;
         }
+    }
+#ifdef RM_STAMPS
+    const unsigned long long t_fb0 = __builtin_amdgcn_s_memtime();
+#endif
+    const double all = all_prims_wave(S, fallback && !served, q, lane, coop, filter);
+#ifdef RM_STAMPS
+    if (dbg_fallback_cycles) *dbg_fallback_cycles += __builtin_amdgcn_s_memtime() - t_fb0;
+#endif
+    if (fallback) {
+        if (!served) closest = all;
+        count += static_cast<uint32_t>(S.n_prims);
+    } else if (need) {
+        count += found;
+    }
+    return closest;
+}
+
+// Scan state of "evaluate once": the sphere with the smallest upper bound and the smallest lower bound of the rest
+struct BestScan {
+    int k1;
+    float hi1, lb1, lb2;
+};
+__device__ __forceinline__ void scan_sphere(BestScan &b, const RmSphere &s, int id, const Vec3f &p) {
+    float err;
+    const float a = sphere_sdf_estimate(s, p, err);
+    const float lb = a - err, hi = a + err;
+    const bool better = hi < b.hi1;
+    b.lb2 = __builtin_fminf(b.lb2, better ? b.lb1 : lb);
+    b.k1 = better ? id : b.k1;
+    b.lb1 = better ? lb : b.lb1;
+    b.hi1 = better ? hi : b.hi1;
+}
+
+// BVH branch of Scene.getDistance (scene.ts:167-181); whole wave must call.  Every source of candidates of a lane
+// -- the leaves whose box contains its point (through the leaf grid or the tree walk) or, when there is none, the
+// cell's nearest-candidate list (scene.ts:173) -- feeds ONE scan; the exact FP64 evaluation then happens once per
+// call, for all lanes together, instead of once per list position at which some lane's bound passes.  Near ties
+// (the runner-up's lower bound does not exceed the exact value) are recomputed by the sequential form above.
+__device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
+                                    uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
+                                    unsigned long long *dbg_fallback_cycles) {
+    if (!filter) return bvh_distance_wave_seq(P, S, need, q, count, lane, coop, filter, use_grid, dbg_fallback_cycles);
+    double closest = RM_MAX_DIST;
+    uint32_t found = 0;
+    bool walk_tree = false;
+    bool in_root = false;
+    BestScan bs;
+    bs.k1 = -1;
+    bs.hi1 = bs.lb1 = bs.lb2 = __builtin_inff();
+    auto scan_leaf = [&](const RmBvhNode &node) {
+        const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
+        for (int k = 0; k < cnt; ++k) {
+            const int id = P.leaf_order ? first + k : S.bvh_prims[first + k];
+            scan_sphere(bs, S.spheres[id], id, q);
+        }
+        found += static_cast<uint32_t>(cnt);
+    };
+    if (need && use_grid) {
+        const RmBvhNode root = S.nodes[0];
+        if (box_contains(root.lo, root.hi, q)) {
+            const int cx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
+            const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
+            const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
+            in_root = true;
+            const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
+            const int ccnt = static_cast<int>(cell & 0xFFu);
+            if (ccnt == 255) walk_tree = true;  // crowded cell: the tree walk below
+            else {
+                const uint16_t *lst = S.pq_list + (cell >> 8);
+                for (int e = 0; e < ccnt; ++e) {
+                    const RmBvhNode node = S.nodes[lst[e]];
+                    if (box_contains(node.lo, node.hi, q)) scan_leaf(node);
+                }
+            }
+        }
+    }
+    if (need && (!use_grid || walk_tree)) {
+        int i = 0;
+        const int n = S.bvh_nodes;
+        while (i < n) {  // BVH.getPrimitivesAt (bvh.ts:95-121), stackless
+            const RmBvhNode node = S.nodes[i];
+            if (!box_contains(node.lo, node.hi, q)) {
+                i = node.skip;
+                continue;
+            }
+            if (node.leaf < 0) {
+                i = i + 1;
+                continue;
+            }
+            scan_leaf(node);
+            i = node.skip;
+        }
+    }
+    const bool fallback = need && found == 0;
+    bool served = false;
+    if (fallback && P.use_nn && in_root) {  // scene.ts:173 through the cell's nearest-candidate list
+        const int nx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.nn_inv[0]), 0), P.nn_dim[0] - 1);
+        const int ny = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.nn_inv[1]), 0), P.nn_dim[1] - 1);
+        const int nz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.nn_inv[2]), 0), P.nn_dim[2] - 1);
+        const uint32_t cell = S.nn_cells[(nz * P.nn_dim[1] + ny) * P.nn_dim[0] + nx];
+        const int ccnt = static_cast<int>(cell & 0xFFu);
+        if (ccnt != 255) {
+            const uint16_t *lst = S.nn_list + (cell >> 8);
+            for (int e = 0; e < ccnt; ++e) {
+                const int id = lst[e];
+                scan_sphere(bs, S.spheres[id], id, q);
+            }
+            served = true;
+        }
+    }
+    // the one exact evaluation of this call
+    bool redo = false;
+    if (bs.k1 >= 0) {
+        closest = sphere_sdf_fast(S.spheres[bs.k1], S.radii[bs.k1], q);
+        if (closest > RM_MAX_DIST) closest = RM_MAX_DIST;  // Math.min(sdf, closestDistance = 10)
+        redo = bs.lb2 <= f32_upper_bound(closest);
+    }
+    if (__any(redo)) {  // near tie somewhere in the wave: those lanes take the sequential form (same result by construction)
+        uint32_t dummy = 0;
+        const double r = bvh_distance_wave_seq(P, S, redo, q, dummy, lane, coop, filter, use_grid, nullptr);
+        if (redo) closest = r;
     }
 #ifdef RM_STAMPS
     const unsigned long long t_fb0 = __builtin_amdgcn_s_memtime();

@@ -48,7 +48,8 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
         for (int k = 0; k < n; ++k) closest = min_dist(prim_sdf_general(P.prims[ids ? ids[k] : k], p), closest);
         return closest;
     }
-    return prims_min<false>(P.spheres, P.radii, ids, n, p, closest, P.filter != 0);
+    if (P.filter && n >= 2) return prims_min_best<int32_t>(P.spheres, P.radii, ids, n, 0, p, closest);  // scan, then one exact evaluation
+    return prims_min<false>(P.spheres, P.radii, ids, n, p, closest, false);
 }
 
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted

@@ -131,7 +131,7 @@ __device__ __forceinline__ float f32_upper_bound(double v) {
 __device__ __forceinline__ float sphere_sdf_estimate(const RmSphere &s, const Vec3f &p, float &err) {
     const float dx = p.x - s.cx, dy = p.y - s.cy, dz = p.z - s.cz;
     const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
-    err = (len + s.rf + 1.0f) * 4e-6f;
+    err = (len + __builtin_fabsf(s.rf) + 1.0f) * 4e-6f;  // |r|: a negative radius is legal input (sphere.ts:12-14 just subtracts it)
     return len - s.rf;
 }
 

@@ -121,7 +121,7 @@ __device__ int oct_find(const RmRenderParams &P, const Vec3f &p) {
 __device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *rec, const Vec3f &p, double &closest, float &ub) {
     const float dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
     const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
-    const float err = (len + c.w + 1.0f) * 4e-6f;  // sphere_sdf_estimate
+    const float err = (len + __builtin_fabsf(c.w) + 1.0f) * 4e-6f;  // sphere_sdf_estimate
     if ((len - c.w) - err <= ub) {
         const double e = hypot3_shared_rcp(dx, dy, dz) - rec->radius;
         if (e < closest) {
@@ -146,7 +146,7 @@ __device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, doubl
     auto scan = [&](const float4 c, int k) {
         const float dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
         const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
-        const float err = (len + c.w + 1.0f) * 4e-6f;  // sphere_sdf_estimate
+        const float err = (len + __builtin_fabsf(c.w) + 1.0f) * 4e-6f;  // sphere_sdf_estimate
         const float a = len - c.w, lb = a - err, hi = a + err;
         const bool better = hi < hi1;
         lb2 = __builtin_fminf(lb2, better ? lb1 : lb);

@@ -116,6 +116,18 @@ def test_random_sphere_scenes_with_candidate_lists(rm, oracle, n, seed):
 
 
 @pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
+def test_degenerate_radii(rm, gpu_ctx, oracle, accel):
+    """Zero and negative radii are legal input (Sphere.localSdf only subtracts the radius): the conservative
+    filter's error term must not shrink with them."""
+    rng = np.random.default_rng(9)
+    sp = np.zeros((60, 4))
+    sp[:, :3] = rng.uniform(-1.2, 1.2, (60, 3)).astype(np.float32)
+    sp[:, 3] = rng.choice([0.0, -0.3, -2.5, 0.2, 0.4, 1e-9], 60)
+    got = gpu_render(rm, gpu_ctx, None, accel, 200, 130, (0.2, 0.4), spheres=sp)
+    assert_same(got, cpu_render(oracle, None, accel, 200, 130, (0.2, 0.4), spheres=sp), "degenerate radii " + accel)
+
+
+@pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
 def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):
     got = gpu_render(rm, gpu_ctx, preset, accel, 200, 150)

@@ -566,6 +566,7 @@ __device__ __forceinline__ const T *stage(unsigned char *smem, size_t &off, cons
 struct TileQueue {
     unsigned int *counters;  // one per XCD, zeroed by the host before the launch
     int tiles_x, tiles_y, tile_w, tile_h, item_px;
+    unsigned int tiles_x_magic;  // floor(2^32 / tiles_x) + 1; 0 for tiles_x == 1
 };
 
 // next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
@@ -575,10 +576,11 @@ __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &ti
         unsigned int k = 0;
         if (lane == 0) k = atomicAdd(&Q.counters[x], 1u);
         k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
-        const int row = static_cast<int>(k / static_cast<unsigned int>(Q.tiles_x)) * 8 + x;
+        const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
+        const int row = static_cast<int>(q) * 8 + x;
         if (row < Q.tiles_y) {
             tile_row = row;
-            tile_col = static_cast<int>(k % static_cast<unsigned int>(Q.tiles_x));
+            tile_col = static_cast<int>(k - q * static_cast<unsigned int>(Q.tiles_x));
             home = x;
             return true;
         }
@@ -693,9 +695,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
             Q.counters = C.tile_counters;
             Q.tile_w = C.tile_w;
             Q.item_px = C.item_px;
-            Q.tile_h = C.item_px / C.tile_w;
-            Q.tiles_x = (C.width + Q.tile_w - 1) / Q.tile_w;
-            Q.tiles_y = (C.local_rows + Q.tile_h - 1) / Q.tile_h;
+            Q.tile_h = 1 << C.tile_h_log2;
+            Q.tiles_x = C.tiles_x;
+            Q.tiles_y = C.tiles_y;
+            Q.tiles_x_magic = C.tiles_x_magic;
             if (phase == PH_DONE && have_pixel) {
                 store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;
@@ -712,8 +715,8 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
                 if (take) {
                     const int n = qpos + rank;  // pixel n of the tile, in 64-pixel sub-tile order
                     const int sub = n >> 6, l = n & 63;
-                    px = tile_col * Q.tile_w + (l % Q.tile_w);
-                    prow = tile_row * Q.tile_h + sub * (64 / Q.tile_w) + (l / Q.tile_w);
+                    px = (tile_col << C.tile_w_log2) + (l & (Q.tile_w - 1));
+                    prow = (tile_row << C.tile_h_log2) + sub * (64 >> C.tile_w_log2) + (l >> C.tile_w_log2);
                     if (px < C.width && prow < C.local_rows) {
                         have_pixel = true;
                         ray = make_ray(C, px, row_to_y(C, prow));
@@ -889,6 +892,13 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     const int tw = p.tile_w, th = p.item_px / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + th - 1) / th;
+    auto log2i = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    if ((tw & (tw - 1)) != 0 || tiles_x <= 0 || static_cast<long long>(tiles_x) * (tiles_y + 8) >= (1ll << 31)) return hipErrorInvalidValue;
+    p.tile_w_log2 = log2i(tw);
+    p.tile_h_log2 = log2i(th);
+    p.tiles_x = tiles_x;
+    p.tiles_y = tiles_y;
+    p.tiles_x_magic = tiles_x == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / static_cast<unsigned long long>(tiles_x)) + 1u;  // 0: k / 1
     const unsigned needed = static_cast<unsigned>((static_cast<long long>(tiles_x) * tiles_y + 3) / 4);  // 4 waves each
     const unsigned resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) *
                               static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);

@@ -133,6 +133,10 @@ struct RmRenderParams {
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;
+    // v2 tile geometry precomputed by the launcher so the refill section has no integer division (tile_w and item_px
+    // are powers of two; k / tiles_x through a magic multiplier, exact for k * tiles_x < 2^32)
+    int32_t tile_w_log2, tile_h_log2, tiles_x, tiles_y;
+    uint32_t tiles_x_magic;
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
     float nn_inv[3];

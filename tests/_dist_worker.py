@@ -32,10 +32,12 @@ def main():
             bpp = D.SECTION_BYTES[name]
             D.FrameLayout.section(layout, pk, name)[local * W * bpp:local * W * bpp + arr.size] = arr
 
-    r = D.ShardedFrameRenderer(layout, rank, world, render_rows, lambda n: torch.zeros(n, dtype=torch.uint8), dist)
+    in_flight = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    r = D.ShardedFrameRenderer(layout, rank, world, render_rows, lambda n: torch.zeros(n, dtype=torch.uint8), dist,
+                               frames_in_flight=in_flight)
     frame = D.new_frame(layout, lambda n: torch.zeros(n, dtype=torch.uint8)) if rank == 0 else None
-    slots = [r.submit() for _ in range(3)]  # three frames through two buffers
-    for s in slots[-2:]:
+    slots = [r.submit() for _ in range(in_flight + 1)]  # one more frame than buffer sets: a set is reused
+    for s in slots[-in_flight:]:
         r.finish(s, frame)
     r.drain()
     ok = True

@@ -17,8 +17,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,mode,stripe", [(2, "interleaved", 16), (2, "contiguous", 16), (3, "interleaved", 4)])
-def test_shard_gather_reassemble(tmp_path, world, mode, stripe):
+@pytest.mark.parametrize("world,mode,stripe,in_flight", [(2, "interleaved", 16, 2), (2, "contiguous", 16, 2),
+                                                         (3, "interleaved", 4, 2), (2, "interleaved", 8, 4)])
+def test_shard_gather_reassemble(tmp_path, world, mode, stripe, in_flight):
     out = tmp_path / "result.txt"
     port = _free_port()
     procs = []
@@ -26,7 +27,7 @@ def test_shard_gather_reassemble(tmp_path, world, mode, stripe):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), mode, str(stripe),
-                                       str(out)], env=env))
+                                       str(out), str(in_flight)], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
     assert out.read_text() == "OK"

@@ -36,6 +36,8 @@ struct DeviceScene {
     int32_t *obj_ranges = nullptr;
     RmSphereRec *oct_recs = nullptr;
     int32_t *oct_lut = nullptr;
+    uint32_t *oct_sub_hdr = nullptr;
+    uint8_t *oct_sub_list = nullptr;
 };
 
 }  // namespace
@@ -80,6 +82,7 @@ struct rm_ctx {
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
+    int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
     int64_t opt_item_px = 64;
     unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
@@ -123,6 +126,8 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.obj_ranges);
     (void)hipFree(d.oct_recs);
     (void)hipFree(d.oct_lut);
+    (void)hipFree(d.oct_sub_hdr);
+    (void)hipFree(d.oct_sub_list);
     d = DeviceScene();
 }
 
@@ -156,6 +161,8 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.obj_ranges, &ctx->dev.obj_ranges))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_recs, &ctx->dev.oct_recs))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_lut, &ctx->dev.oct_lut))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct_sub_hdr, &ctx->dev.oct_sub_hdr))) return rc;
+    if ((rc = upload_vec(ctx, ctx->host.oct_sub_list, &ctx->dev.oct_sub_list))) return rc;
     return RM_OK;
 }
 
@@ -362,6 +369,8 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.oct_prims = ctx->dev.oct_prims;
     p.oct_recs = ctx->opt_recs ? ctx->dev.oct_recs : nullptr;
     p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
+    p.oct_sub_hdr = (ctx->opt_sub && ctx->opt_recs) ? ctx->dev.oct_sub_hdr : nullptr;
+    p.oct_sub_list = ctx->dev.oct_sub_list;
     return RM_OK;
 }
 
@@ -882,6 +891,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lut = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "sub")) {
+        ctx->opt_sub = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "refill")) {
         if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "refill must be in [1, 64]");
         ctx->opt_refill = value;
@@ -926,6 +939,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "refill")) *value = ctx->opt_refill;
     else if (!std::strcmp(key, "recs")) *value = ctx->opt_recs;
     else if (!std::strcmp(key, "lut")) *value = ctx->opt_lut;
+    else if (!std::strcmp(key, "sub")) *value = ctx->opt_sub;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

@@ -138,7 +138,10 @@ __device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *
 // smallest lower bound among all the others (lb2); afterwards every lane evaluates its k1 exactly in the SAME
 // instruction stream.  If lb2 exceeds that exact value no other sphere can be closer (exact_j >= lb_j >= lb2);
 // otherwise (near ties) the list is rescanned with the ordinary filter.  Four 16-B loads are in flight per step.
-__device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, double closest) {
+// `sub` != nullptr: only the listed positions are scanned (the sub-cell's candidates, rm_scene_host.h); the near-tie
+// rescan always covers the whole list.
+__device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, double closest, const uint8_t *sub = nullptr,
+                           int n_sub = 0) {
     if (n <= 0) return closest;
     const float inf = __builtin_inff();
     int k1 = 0;
@@ -155,6 +158,13 @@ __device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, doubl
         hi1 = better ? hi : hi1;
     };
     int k = 0;
+    if (sub) {
+        for (int e = 0; e < n_sub; ++e) {
+            const int j = sub[e];
+            scan(*reinterpret_cast<const float4 *>(recs + j), j);
+        }
+        k = n;  // skip the full scan below
+    }
     for (; k + 4 <= n; k += 4) {
         const float4 c0 = *reinterpret_cast<const float4 *>(recs + k);
         const float4 c1 = *reinterpret_cast<const float4 *>(recs + k + 1);
@@ -185,7 +195,21 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
     const RmOctNode nd = P.oct[node];
     double closest = RM_MAX_DIST;
     if (nd.prim_count > 0) {
-        if (GEN == 0 && P.oct_recs && P.filter) closest = recs_min(P.oct_recs + nd.prim_first, nd.prim_count, p, closest);
+        if (GEN == 0 && P.oct_recs && P.filter) {
+            const uint8_t *sub = nullptr;
+            int n_sub = 0;
+            if (P.oct_sub_hdr && nd.sub_first >= 0) {  // crowded leaf: the candidates of p's sub-cell
+                const float S = static_cast<float>(RM_OCT_SUB);
+                const float ix = S / (nd.hi[0] - nd.lo[0]), iy = S / (nd.hi[1] - nd.lo[1]), iz = S / (nd.hi[2] - nd.lo[2]);
+                const int sx = min(max(static_cast<int>((p.x - nd.lo[0]) * ix), 0), RM_OCT_SUB - 1);
+                const int sy = min(max(static_cast<int>((p.y - nd.lo[1]) * iy), 0), RM_OCT_SUB - 1);
+                const int sz = min(max(static_cast<int>((p.z - nd.lo[2]) * iz), 0), RM_OCT_SUB - 1);
+                const uint32_t hdr = P.oct_sub_hdr[nd.sub_first + (sz * RM_OCT_SUB + sy) * RM_OCT_SUB + sx];
+                sub = P.oct_sub_list + (hdr >> 8);
+                n_sub = static_cast<int>(hdr & 0xFFu);
+            }
+            closest = recs_min(P.oct_recs + nd.prim_first, nd.prim_count, p, closest, sub, n_sub);
+        }
         else closest = list_min<GEN>(P, P.oct_prims + nd.prim_first, nd.prim_count, p, closest);
         count += static_cast<uint32_t>(nd.prim_count);
     } else if (nd.is_empty) {

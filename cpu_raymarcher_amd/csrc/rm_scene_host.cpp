@@ -302,7 +302,7 @@ struct OctBuilder {
         node.is_empty = 1;
         node.min_distance = 0.0;
         node.center[0] = node.center[1] = node.center[2] = 0.0f;
-        node.pad = 0;
+        node.sub_first = -1;
         const int n = static_cast<int>(ids.size());
         if (depth >= 6 || n <= 4) {  // octree.ts:60
             s.oct[me].prim_first = static_cast<int>(s.oct_prims.size());
@@ -486,6 +486,51 @@ static bool build_accel(HostScene &s, int n, std::string &err) {
             for (int32_t v : lut)
                 if (v < 0) ok = false;
             if (ok) s.oct_lut = std::move(lut);
+        }
+        if (!s.general) {  // sub-cell candidate lists of crowded leaves (see rm_scene_host.h)
+            const double margin = 1e-6;
+            for (size_t i = 0; i < s.oct.size(); ++i) {
+                RmOctNode &nd = s.oct[i];
+                const int n = nd.prim_count;
+                if (nd.first_child >= 0 || n <= 8 || n > 255) continue;
+                if (s.oct_sub_list.size() + size_t(RM_OCT_SUB) * RM_OCT_SUB * RM_OCT_SUB * size_t(n) >= (1u << 24)) break;
+                nd.sub_first = static_cast<int32_t>(s.oct_sub_hdr.size());
+                std::vector<double> lb(n);
+                for (int cz = 0; cz < RM_OCT_SUB; ++cz)
+                    for (int cy = 0; cy < RM_OCT_SUB; ++cy)
+                        for (int cx = 0; cx < RM_OCT_SUB; ++cx) {
+                            const int ci[3] = {cx, cy, cz};
+                            double lo[3], hi[3];
+                            for (int k = 0; k < 3; ++k) {  // 3 % slack: the device's binary32 cell index, clamped at the border
+                                const double w = (double(nd.hi[k]) - double(nd.lo[k])) / double(RM_OCT_SUB);
+                                lo[k] = double(nd.lo[k]) + (ci[k] - 0.03) * w;
+                                hi[k] = double(nd.lo[k]) + (ci[k] + 1.03) * w;
+                            }
+                            double U = std::numeric_limits<double>::infinity();
+                            for (int j = 0; j < n; ++j) {
+                                const int id = s.oct_prims[nd.prim_first + j];
+                                const double c[3] = {s.spheres[id].cx, s.spheres[id].cy, s.spheres[id].cz};
+                                double dmin2 = 0, dmax2 = 0;
+                                for (int k = 0; k < 3; ++k) {
+                                    const double below = lo[k] - c[k], above = c[k] - hi[k];
+                                    const double dmin = below > 0 ? below : (above > 0 ? above : 0.0);
+                                    const double dmax = std::max(std::fabs(c[k] - lo[k]), std::fabs(c[k] - hi[k]));
+                                    dmin2 += dmin * dmin;
+                                    dmax2 += dmax * dmax;
+                                }
+                                lb[j] = std::sqrt(dmin2) - s.radii[id];
+                                U = std::min(U, std::sqrt(dmax2) - s.radii[id]);
+                            }
+                            const size_t first = s.oct_sub_list.size();
+                            uint32_t cnt = 0;
+                            for (int j = 0; j < n; ++j)
+                                if (lb[j] <= U + margin) {
+                                    s.oct_sub_list.push_back(static_cast<uint8_t>(j));
+                                    ++cnt;
+                                }
+                            s.oct_sub_hdr.push_back(static_cast<uint32_t>(first << 8) | cnt);
+                        }
+            }
         }
         if (!s.general) {  // leaf-ordered sphere records for the device's leaf loops
             s.oct_recs.resize(s.oct_prims.size());

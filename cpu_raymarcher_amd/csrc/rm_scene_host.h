@@ -66,6 +66,11 @@ struct HostScene {
     // depth 6 (scene.ts:81-85, octree.ts:60), so every leaf is a box of whole 0.3125-cells of a 64^3 grid
     // and every cell boundary -10 + 0.3125 k is exact in binary32.  oct_lut[(z*64 + y)*64 + x] = leaf node.
     std::vector<int32_t> oct_lut;
+    // Crowded octree leaves (> 8 spheres): a grid of RM_OCT_SUB^3 sub-cells, each listing the positions (within the leaf's
+    // list) of the spheres that can attain the leaf's minimum for SOME point of the sub-cell -- the same bound as the
+    // BVH's nearest-candidate grid, but taken over the leaf's own list, which is what Scene.getDistance evaluates.
+    std::vector<uint32_t> oct_sub_hdr;
+    std::vector<uint8_t> oct_sub_list;
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 };

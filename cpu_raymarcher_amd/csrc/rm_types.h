@@ -37,8 +37,10 @@ struct RmOctNode {
     int32_t prim_count;
     int32_t is_empty;
     float center[3];      // f32 split point (boundingBox.ts:108-114) = children[0].hi; internal nodes
-    int32_t pad;
+    int32_t sub_first;    // leaves with many spheres: first of RM_OCT_SUB^3 sub-cell headers in oct_sub_hdr, else -1
 };
+
+#define RM_OCT_SUB 12  // sub-cells per axis of a crowded octree leaf
 
 struct RmSphere {
     float cx, cy, cz;
@@ -158,6 +160,8 @@ struct RmRenderParams {
     const int32_t *oct_prims;
     const RmSphereRec *oct_recs;  // parallel to oct_prims (sphere scenes only, else null)
     const int32_t *oct_lut;       // 64^3 finest-level cells -> leaf node index (null: descend the tree)
+    const uint32_t *oct_sub_hdr;  // per crowded leaf RM_OCT_SUB^3 sub-cells: (offset << 8) | count into oct_sub_list
+    const uint8_t *oct_sub_list;  // positions within the leaf's record list of the spheres that can be nearest there
     uint8_t *depth;
     uint8_t *normal;
     uint16_t *sdf;

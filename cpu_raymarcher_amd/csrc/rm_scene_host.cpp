@@ -237,7 +237,7 @@ void build_point_query_grid(HostScene &s) {
     // The candidate grid is finer than the leaf grid (cell diagonal << sphere spacing keeps the lists at a
     // handful of spheres): up to 48 cells per axis, bounded by the host work cells * n.
     const size_t n = s.spheres.size();
-    if (n == 0 || n >= 65536) return;
+    if (n == 0 || n > 2048) return;  // used for scenes of <= 512 spheres by default (rm_api.cpp), on request up to 2048
     int ng = 48;
     while (ng > 4 && static_cast<unsigned long long>(ng) * ng * ng * n > 40000000ull) ng -= 4;
     size_t ncells = 1;

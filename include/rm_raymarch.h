@@ -283,8 +283,14 @@ RM_API int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *
  * accumulators of the v2 wave loop (all zero in the product build). */
 RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 
-/* kernel-variant knobs for measurement (tile shape, LDS staging ...); unknown keys are
- * RM_E_INVALID.  Never changes results. */
+/* Kernel-variant knobs for measurement; unknown keys or values are RM_E_INVALID.  They NEVER change results
+ * (tests/test_gpu_parity.py renders every combination and compares the bytes).
+ *   kernel 0 auto | 1 one ray per lane (v1) | 2 uniform wave loop (v2)      tile_w 8|16|32|64 pixels per wave row
+ *   filter 0|1 conservative binary32 bound before exact evaluations         coop 0|1 wave-cooperative all-primitive loop
+ *   nodes_in_lds 0|1 scene tables staged in LDS (v2)                        list_cap 1..64 hit-leaf list entries per ray (v2)
+ *   grid 0|1 leaf grid for BVH.getPrimitivesAt (v2)                         nn 0|1|2 nearest-candidate grid off|on|auto
+ *   recs, lut, sub 0|1 octree: leaf-ordered records, findNode cell table, sub-cell candidate lists
+ *   blocks_per_cu 1..8, refill 1..64, hw_xcd 0|1, item_px 64|128|256       persistent-kernel scheduling (v2) */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
 

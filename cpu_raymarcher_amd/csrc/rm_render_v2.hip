@@ -577,8 +577,13 @@ __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &ti
         if (lane == 0) k = atomicAdd(&Q.counters[x], 1u);
         k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
         const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
-        const int row = static_cast<int>(q) * 8 + x;
-        if (row < Q.tiles_y) {
+        // XCD x owns the R tile rows x, x + 8, ...; they are handed out from the middle of the frame outwards, so the
+        // light rows near the top and bottom edges (rays that miss everything) come last and pack the frame's tail
+        const int R = (Q.tiles_y - x + 7) >> 3;
+        const int qi = static_cast<int>(q), mid = R >> 1;
+        const int j = (qi & 1) ? mid - ((qi + 1) >> 1) : mid + (qi >> 1);
+        const int row = j * 8 + x;
+        if (qi < R) {
             tile_row = row;
             tile_col = static_cast<int>(k - q * static_cast<unsigned int>(Q.tiles_x));
             home = x;

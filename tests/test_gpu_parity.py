@@ -84,9 +84,10 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, grid=0), dict(kernel=2, refill=8), dict(kernel=2, refill=24, hw_xcd=0),
                      dict(kernel=2, refill=1, blocks_per_cu=1), dict(kernel=0), dict(kernel=1, recs=0),
                      dict(kernel=1, filter=0), dict(kernel=1, lut=0), dict(kernel=1, sub=0), dict(kernel=2, nn=0),
+                     dict(kernel=2, item_px=64), dict(kernel=2, item_px=256, tile_w=32), dict(kernel=2, item_px=128, tile_w=64),
                      dict(kernel=2, nn=1, coop=0)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)

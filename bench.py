@@ -194,6 +194,13 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+    # With frames in flight a frame's internal balance does not matter (the next frames fill the gaps), so three
+    # quarters of every tile queue are assigned to the waves statically and the queue atomic (a ~10 us device-scope
+    # round trip per 128-pixel item) is paid for the last quarter only.  Alone, a frame is faster with all-dynamic queues.
+    static_share = 75 if (max(1, args.frames_in_flight) > 1 and not args.analytics_sweep
+                          and not any(kv.startswith("static=") for kv in args.opt)) else None
+    if static_share is not None:
+        ctx.set_option("static", static_share)
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
         from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition
@@ -348,6 +355,8 @@ def main():
     if S > 1 and world == 1:
         ser = []
         b = sets[0]
+        if static_share is not None:
+            ctx.set_option("static", 0)  # the launch running alone uses the all-dynamic queues
         with torch.cuda.stream(streams[0]):
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -358,6 +367,8 @@ def main():
                 ser.append((e0, e1))
                 torch.cuda.synchronize()
         kern_serial_ms = sum(a.elapsed_time(c) for a, c in ser) / len(ser)
+        if static_share is not None:
+            ctx.set_option("static", static_share)
     bytes_per_launch = ALG_BYTES_PER_PIXEL * px_per_launch
     if S > 1:
         achieved = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
@@ -400,6 +411,7 @@ def main():
                          if traffic else None,
                          "kernel": "render_kernel_v2<2,true>" if args.workload == "C3" else "render kernel",
                          "kernel_ms": kern_serial_ms, "kernel_ms_in_flight": kern_ms, "frames_in_flight": S,
+                         "static_tile_share_percent": static_share or 0,
                          "achieved_one_launch_alone": achieved_serial,
                          "basis": ("device level: algorithmic bytes per launch x %d launches / wall time of the timed "
                                    "region (%d frames in flight overlap; kernel_ms is the launch running alone, "

@@ -81,6 +81,8 @@ struct rm_ctx {
     int64_t opt_blocks_per_cu = 4;
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
+    int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
+                             // frames overlap (bench.py sets 75 with frames in flight); alone it costs the frame its balance
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
@@ -338,6 +340,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.refill_threshold = static_cast<int32_t>(ctx->opt_refill);
     p.hw_xcd = static_cast<int32_t>(ctx->opt_hw_xcd);
     p.item_px = static_cast<int32_t>(ctx->opt_item_px);
+    p.static_share = static_cast<int32_t>(ctx->opt_static);
     p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 64) : nullptr;
     p.stamps = ctx->d_stamps;
     for (int k = 0; k < 3; ++k) {
@@ -891,6 +894,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lut = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "static")) {
+        if (value < 0 || value > 95) return fail(ctx, RM_E_INVALID, "static must be in [0, 95] percent");
+        ctx->opt_static = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "sub")) {
         ctx->opt_sub = value ? 1 : 0;
         return RM_OK;
@@ -940,6 +948,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "recs")) *value = ctx->opt_recs;
     else if (!std::strcmp(key, "lut")) *value = ctx->opt_lut;
     else if (!std::strcmp(key, "sub")) *value = ctx->opt_sub;
+    else if (!std::strcmp(key, "static")) *value = ctx->opt_static;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

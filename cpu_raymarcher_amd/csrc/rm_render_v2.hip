@@ -567,9 +567,23 @@ struct TileQueue {
     unsigned int *counters;  // one per XCD, zeroed by the host before the launch
     int tiles_x, tiles_y, tile_w, tile_h, item_px;
     unsigned int tiles_x_magic;  // floor(2^32 / tiles_x) + 1; 0 for tiles_x == 1
+    unsigned int base;           // first queue entry handed out dynamically (the ones before it are assigned statically)
 };
 
 // next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
+// entry q of XCD queue x -> tile (row, col); false beyond the queue's end.  XCD x owns the R tile rows x, x + 8, ...;
+// they are handed out from the middle of the frame outwards, so the light rows near the top and bottom edges (rays that
+// miss everything) come last and pack the frame's tail.
+__device__ __forceinline__ bool queue_entry(const TileQueue &Q, int x, unsigned int k, int &tile_col, int &tile_row) {
+    const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
+    const int R = (Q.tiles_y - x + 7) >> 3;
+    const int qi = static_cast<int>(q), mid = R >> 1;
+    const int j = (qi & 1) ? mid - ((qi + 1) >> 1) : mid + (qi >> 1);
+    tile_row = j * 8 + x;
+    tile_col = static_cast<int>(k - q * static_cast<unsigned int>(Q.tiles_x));
+    return qi < R;
+}
+
 // `first_claim`: lane 0's result of an atomicAdd on the home queue that the caller issued earlier (so that its round
 // trip overlaps the pixel stores); the first attempt consumes it instead of issuing its own.
 __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &tile_col, int &tile_row, int lane,
@@ -578,17 +592,8 @@ __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &ti
         const int x = (home + attempt) & 7;
         unsigned int k = first_claim;
         if (attempt > 0 && lane == 0) k = atomicAdd(&Q.counters[x], 1u);
-        k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
-        const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
-        // XCD x owns the R tile rows x, x + 8, ...; they are handed out from the middle of the frame outwards, so the
-        // light rows near the top and bottom edges (rays that miss everything) come last and pack the frame's tail
-        const int R = (Q.tiles_y - x + 7) >> 3;
-        const int qi = static_cast<int>(q), mid = R >> 1;
-        const int j = (qi & 1) ? mid - ((qi + 1) >> 1) : mid + (qi >> 1);
-        const int row = j * 8 + x;
-        if (qi < R) {
-            tile_row = row;
-            tile_col = static_cast<int>(k - q * static_cast<unsigned int>(Q.tiles_x));
+        k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k))) + Q.base;
+        if (queue_entry(Q, x, k, tile_col, tile_row)) {
             home = x;
             return true;
         }
@@ -663,6 +668,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
     // ---- wave state: the tile being consumed ------------------------------------------------
     int tile_col = 0, tile_row = 0, qpos = item_px;  // qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
+    int static_j = 0;
 
     // ---- lane state ------------------------------------------------------------------------
     Ray ray;  // set by the first refill (every lane starts idle)
@@ -707,17 +713,27 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
             Q.tiles_x = C.tiles_x;
             Q.tiles_y = C.tiles_y;
             Q.tiles_x_magic = C.tiles_x_magic;
+            Q.base = static_cast<unsigned int>(C.queue_base);
             // The queue atomic is issued BEFORE the pixel stores and its result consumed after them: the wait for the
             // returned value (s_waitcnt vmcnt counts in order) then no longer covers the completion of the seven stores,
             // which was 23 % of the wave cycles in the stamps build.
             const bool want_tile = !no_more && qpos >= Q.item_px;
+            const bool want_static = want_tile && static_j < C.static_per_wave;
             unsigned int claim = 0;
-            if (want_tile && lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
+            if (want_tile && !want_static && lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
             if (phase == PH_DONE && have_pixel) {
                 store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;
             }
-            if (want_tile) {
+            if (want_static) {  // no atomic: workgroup b serves queue b % 8 (the XCD it is dispatched to under round-robin
+                                // placement; coverage does not depend on that), its wave w the entries rank + waves/8 * j
+                const int x = static_cast<int>(blockIdx.x) & 7;
+                const unsigned int k = static_cast<unsigned int>(((static_cast<int>(blockIdx.x) >> 3) << 2) + wave +
+                                                                 (C.total_waves >> 3) * static_j);
+                static_j += 1;
+                queue_entry(Q, x, k, tile_col, tile_row);
+                qpos = 0;
+            } else if (want_tile) {
                 if (pull_tile(Q, home, tile_col, tile_row, lane, claim)) qpos = 0;
                 else no_more = true;
             }
@@ -917,6 +933,17 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     const unsigned resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) *
                               static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
     const unsigned blocks = needed < resident ? (needed ? needed : 1u) : resident;
+    // static share: three quarters of the shortest queue, in whole rounds over all waves
+    p.total_waves = static_cast<int32_t>(blocks * 4);
+    p.static_per_wave = 0;
+    p.queue_base = 0;
+    if (p.static_share > 0 && blocks % 8 == 0) {
+        const long long min_rows = tiles_y / 8;  // every queue owns at least this many tile rows
+        const long long per_round = p.total_waves / 8;  // queue entries one round of all waves consumes per queue
+        const long long rounds = (min_rows * tiles_x * p.static_share / 100) / per_round;
+        p.static_per_wave = static_cast<int32_t>(rounds);
+        p.queue_base = static_cast<int32_t>(rounds * per_round);
+    }
     if (p.list_cap < 1) p.list_cap = 1;
     if (p.refill_threshold < 1) p.refill_threshold = 1;
     if (p.refill_threshold > 64) p.refill_threshold = 64;

@@ -139,6 +139,10 @@ struct RmRenderParams {
     // are powers of two; k / tiles_x through a magic multiplier, exact for k * tiles_x < 2^32)
     int32_t tile_w_log2, tile_h_log2, tiles_x, tiles_y;
     uint32_t tiles_x_magic;
+    // v2: the first `static_per_wave` items of every wave are assigned without an atomic (wave g takes entries
+    // g + total_waves * j of the interleaved queues); the queues hand out the rest, starting at queue_base
+    int32_t static_per_wave, queue_base, total_waves;
+    int32_t static_share;  // percent of the shortest queue assigned statically (option; 0 = all dynamic)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
     float nn_inv[3];

@@ -290,7 +290,8 @@ RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
  *   nodes_in_lds 0|1 scene tables staged in LDS (v2)                        list_cap 1..64 hit-leaf list entries per ray (v2)
  *   grid 0|1 leaf grid for BVH.getPrimitivesAt (v2)                         nn 0|1|2 nearest-candidate grid off|on|auto
  *   recs, lut, sub 0|1 octree: leaf-ordered records, findNode cell table, sub-cell candidate lists
- *   blocks_per_cu 1..8, refill 1..64, hw_xcd 0|1, item_px 64|128|256       persistent-kernel scheduling (v2) */
+ *   blocks_per_cu 1..8, refill 1..64, hw_xcd 0|1, item_px 64|128|256       persistent-kernel scheduling (v2)
+ *   static 0..95 percent of every tile queue assigned to the waves without atomics (v2; for overlapping frames) */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
 

@@ -85,9 +85,10 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, refill=1, blocks_per_cu=1), dict(kernel=0), dict(kernel=1, recs=0),
                      dict(kernel=1, filter=0), dict(kernel=1, lut=0), dict(kernel=1, sub=0), dict(kernel=2, nn=0),
                      dict(kernel=2, item_px=64), dict(kernel=2, item_px=256, tile_w=32), dict(kernel=2, item_px=128, tile_w=64),
+                     dict(kernel=2, static=75), dict(kernel=2, static=95, item_px=64),
                      dict(kernel=2, nn=1, coop=0)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -95,6 +96,22 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
         for o in outs[1:]:
             assert_same(o, outs[0], "%s %s variants" % (preset, accel))
         assert_same(outs[0], cpu_render(oracle, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres), "vs oracle")
+
+
+def test_static_tile_share_on_a_frame_large_enough_to_use_it(rm):
+    """The statically assigned part of the tile queues only exists when a frame has more items than one round
+    over all waves: 1920x1080 gives two rounds.  Every share must produce the same bytes."""
+    ctx = rm.Context(0)
+    outs = []
+    for opts in (dict(static=0), dict(static=75), dict(static=95), dict(static=75, item_px=64), dict(static=50, tile_w=32)):
+        for k, v in dict(kernel=2, static=0, item_px=128, tile_w=16).items():
+            ctx.set_option(k, v)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        outs.append(gpu_render(rm, ctx, 3, "BVH", 1920, 1080, (0.1, 0.3)))
+    for o in outs[1:]:
+        assert_same(o, outs[0], "static tile share")
+    ctx.close()
 
 
 @pytest.mark.parametrize("n,seed", [(30, 1), (120, 2), (300, 3), (500, 4)])

@@ -98,6 +98,47 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
         assert_same(outs[0], cpu_render(oracle, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres), "vs oracle")
 
 
+def test_frames_in_flight_on_separate_streams(rm):
+    """bench.py keeps several frames in flight: one context, one HIP stream and buffer set per frame, different
+    cameras.  Every frame must equal the same frame rendered alone (tile-counter ring, per-launch parameters)."""
+    import torch
+    W, H = 1280, 720
+    dev = torch.device("cuda:0")
+    ctx = rm.Context(0)
+    ctx.set_option("static", 75)
+    scene = rm.Scene("BVH", ctx=ctx)
+    scene.loadPreset(3)
+    tracer = rm.SphereTracer()
+    yaws = [0.05 * k for k in range(8)]
+
+    def buffers():
+        return dict(depth=torch.zeros(W * H, dtype=torch.uint8, device=dev), normal=torch.zeros(3 * W * H, dtype=torch.uint8, device=dev),
+                    sdf=torch.zeros(W * H, dtype=torch.int16, device=dev), iters=torch.zeros(W * H, dtype=torch.int16, device=dev),
+                    rgba=torch.zeros(4 * W * H, dtype=torch.uint8, device=dev))
+
+    def render(b, yaw):
+        scene.camera.setAngles(0.1, yaw)
+        tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0, shadedBuffer=b["rgba"], shader="phong")
+
+    alone = []
+    for yaw in yaws:
+        b = buffers()
+        render(b, yaw)
+        torch.cuda.synchronize()
+        alone.append({k: v.clone() for k, v in b.items()})
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    sets = [buffers() for _ in yaws]
+    for rep in range(3):  # every stream is reused while the others are busy
+        for k, yaw in enumerate(yaws):
+            with torch.cuda.stream(streams[k % 4]):
+                render(sets[k], yaw)
+    torch.cuda.synchronize()
+    for k in range(len(yaws)):
+        for name in sets[k]:
+            assert torch.equal(sets[k][name], alone[k][name]), (k, name)
+    ctx.close()
+
+
 def test_static_tile_share_on_a_frame_large_enough_to_use_it(rm):
     """The statically assigned part of the tile queues only exists when a frame has more items than one round
     over all waves: 1920x1080 gives two rounds.  Every share must produce the same bytes."""

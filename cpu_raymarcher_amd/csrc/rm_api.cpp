@@ -87,7 +87,8 @@ struct rm_ctx {
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
     int64_t opt_item_px = 128;  // two 64-pixel batches per queue claim: 7-10 % faster than 64 at the end of round 1, 256 loses
-    unsigned int *d_counters = nullptr;  // ring of 64 x 8 queue heads
+    unsigned int *d_counters = nullptr;  // ring of 1024 x 8 queue heads: a launch owns its slot until 1023 later launches
+                                         // have been enqueued (frames in flight on several streams each need their own)
     unsigned int counter_slot = 0;
     unsigned long long *d_stamps = nullptr;  // diagnostic build only
     int num_cus = 256;
@@ -341,7 +342,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.hw_xcd = static_cast<int32_t>(ctx->opt_hw_xcd);
     p.item_px = static_cast<int32_t>(ctx->opt_item_px);
     p.static_share = static_cast<int32_t>(ctx->opt_static);
-    p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 64) : nullptr;
+    p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 1024) : nullptr;
     p.stamps = ctx->d_stamps;
     for (int k = 0; k < 3; ++k) {
         p.pq_dim[k] = ctx->host.pq_dim[k];
@@ -401,7 +402,7 @@ int rm_create(int device, rm_ctx **out) {
         e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 64 * 8 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), 8 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, 8 * sizeof(unsigned long long));
         if (e != hipSuccess) {

@@ -217,6 +217,21 @@ class GpuFrameAssembler:
                 local_of_row[a:b] = torch.arange(loc, loc + b - a)
                 loc += b - a
         self.rank_of_row, self.local_of_row = rank_of_row.to(device), local_of_row.to(device)
+        # One gather kernel per section: the gathered [world, nbytes] buffer is read as units of U bytes (U divides the
+        # row size and the 256-byte section alignment); unit_index[s][y * upr + j] is the unit that holds bytes
+        # [j*U, (j+1)*U) of frame row y.  Sections whose rows do not split into units of >= 16 bytes keep the
+        # two-step indexed copy.
+        import math
+        self.unit, self.unit_index = {}, {}
+        for s in layout.sections:
+            row_bytes = SECTION_BYTES[s] * W
+            U = math.gcd(row_bytes, 256)
+            if U < 16:
+                continue
+            upr = row_bytes // U
+            base = (rank_of_row * layout.nbytes + layout.offsets[s] + local_of_row * row_bytes) // U
+            self.unit[s] = U
+            self.unit_index[s] = (base[:, None] + torch.arange(upr)[None, :]).reshape(-1).to(device)
         self.recv2d = [torch.zeros(layout.world, layout.nbytes, dtype=torch.uint8, device=device) for _ in range(nbuf)]
         # one output frame per buffer set: frames in flight on different streams must not share it
         self.frames = [{s: torch.zeros(SECTION_BYTES[s] * W * H, dtype=torch.uint8, device=device)
@@ -233,7 +248,12 @@ class GpuFrameAssembler:
         for s in L.sections:
             bpp = SECTION_BYTES[s]
             off = L.offsets[s]
-            src = self.recv2d[slot][:, off:off + L.cap * W * bpp].unflatten(1, (L.cap, W * bpp))
-            self.frames[slot][s].view(H, W * bpp).copy_(src[self.rank_of_row, self.local_of_row])
+            if s in self.unit:  # one gather kernel straight into the frame, no temporary
+                U = self.unit[s]
+                self.torch.index_select(self.recv2d[slot].view(-1, U), 0, self.unit_index[s],
+                                        out=self.frames[slot][s].view(-1, U))
+            else:
+                src = self.recv2d[slot][:, off:off + L.cap * W * bpp].unflatten(1, (L.cap, W * bpp))
+                self.frames[slot][s].view(H, W * bpp).copy_(src[self.rank_of_row, self.local_of_row])
         self.frame = self.frames[slot]
         return self.frame

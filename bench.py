@@ -197,10 +197,15 @@ def main():
     # With frames in flight a frame's internal balance does not matter (the next frames fill the gaps), so three
     # quarters of every tile queue are assigned to the waves statically and the queue atomic (a ~10 us device-scope
     # round trip per 128-pixel item) is paid for the last quarter only.  Alone, a frame is faster with all-dynamic queues.
-    static_share = 75 if (max(1, args.frames_in_flight) > 1 and not args.analytics_sweep
+    static_share = 75 if (max(1, args.frames_in_flight) > 1 and not args.analytics_sweep and world == 1
                           and not any(kv.startswith("static=") for kv in args.opt)) else None
     if static_share is not None:
         ctx.set_option("static", static_share)
+    # A rank's shard of a sharded frame is small (1/N of the rows): with frames in flight it runs best with half as
+    # many persistent workgroups per launch and all-dynamic queues (scripts/overlap_probe.py: the 1/8-row shard 0.46 ->
+    # 0.34 ms per frame, 1/4 0.62 -> 0.52, 1/2 1.27 -> 1.09).
+    if world > 1 and not any(kv.startswith("blocks_per_cu=") for kv in args.opt):
+        ctx.set_option("blocks_per_cu", 2)
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
         from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition

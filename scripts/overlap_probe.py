@@ -14,18 +14,23 @@ from cpu_raymarcher_amd import distributed as D
 
 
 def main():
-    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 300
+    opts = [a for a in sys.argv[1:] if "=" in a and not a.startswith("N=")]
     W, H = 3840, 2160
     dev = torch.device("cuda:0")
     ctx = R.Context(0)
+    for kv in opts:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    print("options", opts, flush=True)
     scene = R.Scene("BVH", ctx=ctx)
     scene.loadPreset(3)
-    for world, sections in ((1, ("rgba", "sdf", "iters")), (1, ("depth", "normal", "rgba", "sdf", "iters")),
-                            (1, ("depth", "rgba", "sdf", "iters")), (8, ("rgba", "sdf", "iters"))):
+    worlds = [int(a[2:]) for a in sys.argv[1:] if a.startswith("N=")] or [1, 8]
+    for world, sections in [(w, ("rgba", "sdf", "iters")) for w in worlds]:
         layout = D.FrameLayout(W, H, world, sections, "interleaved", 16)
         print("sections", sections, flush=True)
         render_all = D.gpu_render_all(ctx, scene, W, H, "iteration-heatmap", layout, 0)
-        for nstreams in (1, 4, 6):
+        for nstreams in (1, 6):
             streams = [torch.cuda.Stream() for _ in range(nstreams)]
             packed = [torch.zeros(layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
             accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(nstreams)]

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librm_hip.so")
+# RM_HIP_LIB: another build of the same library (A/B measurements of two builds in one process each)
+LIB_PATH = os.environ.get("RM_HIP_LIB") or os.path.join(_PKG, "librm_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 RM_OK = 0
@@ -102,6 +103,7 @@ SIGNATURES = {
     "rm_selftest_hypot": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "rm_selftest_fastdiv": (C.c_int, [_VP, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]),
     "rm_debug_read_stamps": (C.c_int, [_VP, _VP]),
+    "rm_debug_read_counts": (C.c_int, [_VP, _VP]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
     "rm_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
 }

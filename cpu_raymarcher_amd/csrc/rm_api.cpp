@@ -84,6 +84,7 @@ struct rm_ctx {
     int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
                              // frames overlap (bench.py sets 75 with frames in flight); alone it costs the frame its balance
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
+    int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
     int64_t opt_item_px = 128;  // two 64-pixel batches per queue claim: 7-10 % faster than 64 at the end of round 1, 256 loses
@@ -361,6 +362,15 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     const bool nn_on = ctx->opt_nn == 1 || (ctx->opt_nn == 2 && ctx->host.spheres.size() <= 512);
     p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
     p.leaf_order = ctx->host.leaf_order ? 1 : 0;
+    p.uniform_radius = 0;
+    if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2) {  // one radius, bit for bit
+        const auto &sp = ctx->host.spheres;
+        const auto &rd = ctx->host.radii;
+        bool same = rd.size() == sp.size();
+        for (size_t k = 1; same && k < sp.size(); ++k)
+            same = std::memcmp(&sp[k].rf, &sp[0].rf, sizeof(float)) == 0 && std::memcmp(&rd[k], &rd[0], sizeof(double)) == 0;
+        p.uniform_radius = same ? 1 : 0;
+    }
     for (int k = 0; k < 3; ++k) {
         p.nn_dim[k] = ctx->host.nn_dim[k];
         p.nn_inv[k] = ctx->host.nn_inv[k];
@@ -403,8 +413,8 @@ int rm_create(int device, rm_ctx **out) {
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), 8 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), 40 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, 40 * sizeof(unsigned long long));
         if (e != hipSuccess) {
             delete ctx;
             return RM_E_HIP;
@@ -858,6 +868,16 @@ int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8) {
     return RM_OK;
 }
 
+int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32) {
+    if (!ctx || !out32) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());
+    RM_HIP(ctx, hipMemcpy(out32, ctx->d_stamps + 8, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    RM_HIP(ctx, hipMemset(ctx->d_stamps + 8, 0, 32 * sizeof(uint64_t)));
+    return RM_OK;
+}
+
 int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return RM_E_INVALID;
     if (!std::strcmp(key, "tile_w")) {
@@ -893,6 +913,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "lut")) {
         ctx->opt_lut = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "uniform")) {
+        ctx->opt_uniform = value ? 1 : 0;
         return RM_OK;
     }
     if (!std::strcmp(key, "static")) {
@@ -950,6 +974,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "lut")) *value = ctx->opt_lut;
     else if (!std::strcmp(key, "sub")) *value = ctx->opt_sub;
     else if (!std::strcmp(key, "static")) *value = ctx->opt_static;
+    else if (!std::strcmp(key, "uniform")) *value = ctx->opt_uniform;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

@@ -52,6 +52,25 @@ using namespace rmd;
 #define RM_TEND()
 #endif
 
+// Diagnostic build only (-DRM_COUNTS): how often each part of the wave loop executes -- per event the number of
+// wave-level executions (slot i) and the number of lanes active in them (slot i + 16), accumulated in LDS and added
+// to P.stamps[8 .. 39] at the end.  Instructions per launch ~ sum over events of executions x the event's static
+// instruction count; lanes / (64 x executions) is the event's lane utilisation.
+#ifdef RM_COUNTS
+__shared__ unsigned int rm_cnt_s[32];
+#define RM_CNT(i)                                                                                  \
+    {                                                                                              \
+        const unsigned int n_ = static_cast<unsigned int>(__popcll(__ballot(1)));                  \
+        const int l_ = static_cast<int>(__lane_id());                                              \
+        if (__builtin_amdgcn_readfirstlane(l_) == l_) {                                            \
+            atomicAdd(&rm_cnt_s[i], 1u);                                                           \
+            atomicAdd(&rm_cnt_s[(i) + 16], n_);                                                    \
+        }                                                                                          \
+    }
+#else
+#define RM_CNT(i) {}
+#endif
+
 enum Phase : int { PH_MARCH = 0, PH_N0 = 1, PH_N1 = 2, PH_N2 = 3, PH_N3 = 4, PH_DONE = 5 };
 
 struct SceneView {
@@ -196,6 +215,7 @@ __device__ double all_prims_wave(const SceneView &S, bool need, const Vec3f &q, 
         while (fb) {
             const int src = __builtin_ctzll(fb);
             fb &= fb - 1;
+            RM_CNT(12)
             Vec3f b;
             b.x = readlane_f32(q.x, src);
             b.y = readlane_f32(q.y, src);
@@ -302,7 +322,20 @@ struct BestScan {
     int k1;
     float hi1, lb1, lb2;
 };
+// UR (every sphere of the scene has the same radius): distance order = order of the squared centre distances, so
+// the scan ranks by s2 = |p - c|^2 (hi1 holds the smallest, lb2 the smallest of the others) and the square root,
+// the radius and the error margin are applied once, after the scan (scan_finish), instead of once per sphere.
+template <bool UR>
 __device__ __forceinline__ void scan_sphere(BestScan &b, const RmSphere &s, int id, const Vec3f &p) {
+    if (UR) {
+        const float dx = p.x - s.cx, dy = p.y - s.cy, dz = p.z - s.cz;
+        const float s2 = dx * dx + dy * dy + dz * dz;
+        const bool better = s2 < b.hi1;
+        b.lb2 = __builtin_fminf(b.lb2, better ? b.hi1 : s2);
+        b.k1 = better ? id : b.k1;
+        b.hi1 = __builtin_fminf(b.hi1, s2);
+        return;
+    }
     float err;
     const float a = sphere_sdf_estimate(s, p, err);
     const float lb = a - err, hi = a + err;
@@ -312,12 +345,21 @@ __device__ __forceinline__ void scan_sphere(BestScan &b, const RmSphere &s, int 
     b.lb1 = better ? lb : b.lb1;
     b.hi1 = better ? hi : b.hi1;
 }
+// UR: lb2 (the runner-up's squared centre distance) -> the conservative lower bound sphere_sdf_estimate would have
+// given that sphere.  Every other sphere j has s2_j >= lb2, and the bound is monotone in s2 up to the two ulps of
+// v_sqrt_f32 and of the subtraction, which the margin (12x the worst-case error of the estimate) absorbs.
+__device__ __forceinline__ void scan_finish_uniform(BestScan &b, float rf) {
+    const float len = __builtin_amdgcn_sqrtf(b.lb2);
+    const float lb = (len - rf) - (len + __builtin_fabsf(rf) + 1.0f) * 4e-6f;
+    b.lb2 = b.lb2 < __builtin_inff() ? lb : __builtin_inff();
+}
 
 // BVH branch of Scene.getDistance (scene.ts:167-181); whole wave must call.  Every source of candidates of a lane
 // -- the leaves whose box contains its point (through the leaf grid or the tree walk) or, when there is none, the
 // cell's nearest-candidate list (scene.ts:173) -- feeds ONE scan; the exact FP64 evaluation then happens once per
 // call, for all lanes together, instead of once per list position at which some lane's bound passes.  Near ties
 // (the runner-up's lower bound does not exceed the exact value) are recomputed by the sequential form above.
+template <bool UR>
 __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
                                     uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
                                     unsigned long long *dbg_fallback_cycles) {
@@ -333,7 +375,8 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
         const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
         for (int k = 0; k < cnt; ++k) {
             const int id = P.leaf_order ? first + k : S.bvh_prims[first + k];
-            scan_sphere(bs, S.spheres[id], id, q);
+            RM_CNT(8)
+            scan_sphere<UR>(bs, S.spheres[id], id, q);
         }
         found += static_cast<uint32_t>(cnt);
     };
@@ -350,6 +393,7 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             else {
                 const uint16_t *lst = S.pq_list + (cell >> 8);
                 for (int e = 0; e < ccnt; ++e) {
+                    RM_CNT(7)
                     const RmBvhNode node = S.nodes[lst[e]];
                     if (box_contains(node.lo, node.hi, q)) scan_leaf(node);
                 }
@@ -385,7 +429,8 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             const uint16_t *lst = S.nn_list + (cell >> 8);
             for (int e = 0; e < ccnt; ++e) {
                 const int id = lst[e];
-                scan_sphere(bs, S.spheres[id], id, q);
+                RM_CNT(9)
+                scan_sphere<UR>(bs, S.spheres[id], id, q);
             }
             served = true;
         }
@@ -393,11 +438,15 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
     // the one exact evaluation of this call
     bool redo = false;
     if (bs.k1 >= 0) {
-        closest = sphere_sdf_fast(S.spheres[bs.k1], S.radii[bs.k1], q);
+        RM_CNT(10)
+        const RmSphere s1 = S.spheres[bs.k1];
+        if (UR) scan_finish_uniform(bs, s1.rf);
+        closest = sphere_sdf_fast(s1, S.radii[bs.k1], q);
         if (closest > RM_MAX_DIST) closest = RM_MAX_DIST;  // Math.min(sdf, closestDistance = 10)
         redo = bs.lb2 <= f32_upper_bound(closest);
     }
     if (__any(redo)) {  // near tie somewhere in the wave: those lanes take the sequential form (same result by construction)
+        if (redo) RM_CNT(11)
         uint32_t dummy = 0;
         const double r = bvh_distance_wave_seq(P, S, redo, q, dummy, lane, coop, filter, use_grid, nullptr);
         if (redo) closest = r;
@@ -405,6 +454,7 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
 #ifdef RM_STAMPS
     const unsigned long long t_fb0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (fallback && !served) RM_CNT(13)
     const double all = all_prims_wave(S, fallback && !served, q, lane, coop, filter);
 #ifdef RM_STAMPS
     if (dbg_fallback_cycles) *dbg_fallback_cycles += __builtin_amdgcn_s_memtime() - t_fb0;
@@ -457,6 +507,7 @@ struct RayList {
     uint16_t *col;  // this lane's column: entry e at col[e * 64]
     int cap;
     int cnt;        // leaves hit (may exceed cap -> overflow)
+    int live;       // entries still listed: bvh_next drops the ones that can no longer be a successor
 };
 
 // BVH.onRayMarchStart (bvh.ts:181-202): one traversal; records hit leaves, returns the first
@@ -467,6 +518,7 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
     const int n = S.bvh_nodes;
     L.cnt = 0;
     while (i < n) {
+        RM_CNT(5)
         const RmBvhNode node = S.nodes[i];
         double tE, tX;
         if (!slab_inv(node.lo, node.hi, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
@@ -491,15 +543,23 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
         }
         i = node.skip;
     }
+    L.live = L.cnt;
     return have;
 }
 
 // successor of key (keyT, keyOrd) in the stable-sorted interval order of bvh.ts:176
-__device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, const RayList &L, double keyT, int keyOrd,
+__device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, RayList &L, double keyT, int keyOrd,
                          Interval &out) {
     bool have = false;
+    RM_CNT(3)
     if (L.cnt <= L.cap) {
-        for (int e = 0; e < L.cnt; ++e) {
+        // Keys only grow over a ray's life, so an entry that is not after this key is not after any later one: it
+        // is dropped (the last live entry takes its place), and the list a ray scans shrinks as the ray advances.
+        // The list is then no longer in traversal order, so ties between equal tEnter go to the smaller node index
+        // explicitly (traversal order = increasing index: the stackless walk only moves forward).
+        int e = 0;
+        while (e < L.live) {
+            RM_CNT(4)
             const int id = L.col[e * 64];
             const RmBvhNode node = S.nodes[id];
             double tE, tX;
@@ -507,12 +567,18 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, con
             const double cE = __builtin_fmax(tE, 0.0);
             const double cX = __builtin_fmin(tX, RM_MAX_DIST);
             const bool after = cE > keyT || (cE == keyT && id > keyOrd);
-            if (after && (!have || cE < out.tEnter)) {  // list is in traversal order: first seen wins ties
+            if (!after) {
+                L.live -= 1;
+                L.col[e * 64] = L.col[L.live * 64];
+                continue;
+            }
+            if (!have || cE < out.tEnter || (cE == out.tEnter && id < out.ord)) {
                 out.tEnter = cE;
                 out.tExit = cX;
                 out.ord = id;
                 have = true;
             }
+            e += 1;
         }
         return have;
     }
@@ -617,7 +683,7 @@ __device__ __forceinline__ RmRenderParams cold_params() {
 #endif
 }
 
-template <int ACCEL, bool LDS>
+template <int ACCEL, bool LDS, bool UR = false>
 __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -657,6 +723,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
     RayList L;
     L.cap = P.list_cap;
     L.cnt = 0;
+    L.live = 0;
     L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
     const bool coop = P.coop != 0, filter = P.filter != 0;
 
@@ -697,13 +764,19 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
     };
 
     RM_T0()
+#ifdef RM_COUNTS
+    if (threadIdx.x < 32) rm_cnt_s[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     for (;;) {
         RM_T(7)
+        RM_CNT(0)
         // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
         // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
         const unsigned long long idle = __ballot(phase == PH_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle >= refill_at || n_idle == 64) {
+            RM_CNT(1)
             const RmRenderParams C = cold_params();
             TileQueue Q;
             Q.counters = C.tile_counters;
@@ -757,6 +830,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
                         nx = ny = nz = 0.f;
                         phase = PH_MARCH;
                         if (ACCEL == 2) {
+                            RM_CNT(15)
                             ri = make_ray_inv(ray);
 #ifdef RM_STAMPS
                             const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
@@ -796,6 +870,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
                     break;
                 }
                 loopi++;
+                RM_CNT(2)
                 const Vec3f p = point_at(ray, t);
                 if (ACCEL == 2) {
                     // BVH.onRayMarchStep (bvh.ts:204-240)
@@ -842,6 +917,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
             }
         }
         if (phase >= PH_N0 && phase <= PH_N3) {  // raymarcher.ts:123-132 sample points
+            RM_CNT(14)
             q = point_at(ray, t);  // hitPosition (raymarcher.ts:94-95), recomputed: 3 VGPRs fewer
             if (phase == PH_N1) q.x = to_f32(static_cast<double>(q.x) - 0.01);
             if (phase == PH_N2) q.y = to_f32(static_cast<double>(q.y) - 0.01);
@@ -853,15 +929,16 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
         if (!__any(need)) continue;  // every live ray just finished: go and refill
 
         // ---- B: one Scene.getDistance per needing lane --------------------------------------
+        if (need) RM_CNT(6)
         double dist;
         if (ACCEL == 2) {
 #ifdef RM_STAMPS
             unsigned long long fbc = 0;
-            dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid, &fbc);
+            dist = bvh_distance_wave<UR>(P, S, need, q, count, lane, coop, filter, use_grid, &fbc);
             t_acc_[4] += fbc;
             t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
 #else
-            dist = bvh_distance_wave(P, S, need, q, count, lane, coop, filter, use_grid, nullptr);
+            dist = bvh_distance_wave<UR>(P, S, need, q, count, lane, coop, filter, use_grid, nullptr);
 #endif
         }
         else if (ACCEL == 1) dist = need ? oct_distance_lane(S, onode, q, count, filter) : RM_MAX_DIST;
@@ -895,6 +972,10 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
         RM_T(3)
     }
     RM_TEND()
+#ifdef RM_COUNTS
+    __syncthreads();
+    if (threadIdx.x < 32 && P.stamps) atomicAdd(&P.stamps[8 + threadIdx.x], static_cast<unsigned long long>(rm_cnt_s[threadIdx.x]));
+#endif
 }
 
 size_t scene_lds_bytes(const RmRenderParams &p) {
@@ -956,7 +1037,11 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const dim3 grid(blocks), block(256);
 #define RM_V2(A, L) hipLaunchKernelGGL((render_kernel_v2<A, L>), grid, block, shmem, stream, p)
-    if (p.accel == 2) { if (lds) RM_V2(2, true); else RM_V2(2, false); }
+    if (p.accel == 2) {
+        if (lds && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true>), grid, block, shmem, stream, p);
+        else if (lds) RM_V2(2, true);
+        else RM_V2(2, false);
+    }
     else if (p.accel == 1) { if (lds) RM_V2(1, true); else RM_V2(1, false); }
     else { if (lds) RM_V2(0, true); else RM_V2(0, false); }
 #undef RM_V2

@@ -148,7 +148,7 @@ struct RmRenderParams {
     float nn_inv[3];
     int32_t algorithm;   // rm_algorithm; 0 = sphere tracer, 1..4 the other marchers (v1 kernel)
     int32_t general;     // 0: RmSphere records; 1: RmPrim records (`prims`); 2: expression programs (`prog`); 3: programs with a Mandelbulb
-    int32_t reserved3;
+    int32_t uniform_radius;  // v2: every sphere has the same radius (candidates are ranked by squared centre distance)
     const RmPrim *prims;
     const RmInstr *prog;         // general == 2: instructions of every scene object, concatenated
     const int32_t *obj_ranges;   // general == 2: (first, count) into prog per scene object

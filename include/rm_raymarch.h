@@ -283,6 +283,10 @@ RM_API int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *
  * accumulators of the v2 wave loop (all zero in the product build). */
 RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 
+/* Diagnostic builds only (make EXTRA=-DRM_COUNTS): reads and clears the execution counts of sixteen events of the
+ * v2 wave loop -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
+RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
+
 /* Kernel-variant knobs for measurement; unknown keys or values are RM_E_INVALID.  They NEVER change results
  * (tests/test_gpu_parity.py renders every combination and compares the bytes).
  *   kernel 0 auto | 1 one ray per lane (v1) | 2 uniform wave loop (v2)      tile_w 8|16|32|64 pixels per wave row
@@ -291,7 +295,8 @@ RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
  *   grid 0|1 leaf grid for BVH.getPrimitivesAt (v2)                         nn 0|1|2 nearest-candidate grid off|on|auto
  *   recs, lut, sub 0|1 octree: leaf-ordered records, findNode cell table, sub-cell candidate lists
  *   blocks_per_cu 1..8, refill 1..64, hw_xcd 0|1, item_px 64|128|256       persistent-kernel scheduling (v2)
- *   static 0..95 percent of every tile queue assigned to the waves without atomics (v2; for overlapping frames) */
+ *   static 0..95 percent of every tile queue assigned to the waves without atomics (v2; for overlapping frames)
+ *   uniform 0|1   scenes whose spheres share one radius: rank leaf candidates by squared centre distance (v2, default 1) */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
 

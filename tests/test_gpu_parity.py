@@ -86,9 +86,9 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=1, filter=0), dict(kernel=1, lut=0), dict(kernel=1, sub=0), dict(kernel=2, nn=0),
                      dict(kernel=2, item_px=64), dict(kernel=2, item_px=256, tile_w=32), dict(kernel=2, item_px=128, tile_w=64),
                      dict(kernel=2, static=75), dict(kernel=2, static=95, item_px=64),
-                     dict(kernel=2, nn=1, coop=0)]:
+                     dict(kernel=2, nn=1, coop=0), dict(kernel=2, uniform=0), dict(kernel=2, uniform=0, list_cap=2)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -96,6 +96,34 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
         for o in outs[1:]:
             assert_same(o, outs[0], "%s %s variants" % (preset, accel))
         assert_same(outs[0], cpu_render(oracle, preset, accel, 300, 170, (0.25, 0.6), spheres=spheres), "vs oracle")
+
+
+def test_one_radius_scenes_rank_by_squared_distance(rm, oracle):
+    """Scenes whose spheres share one radius take the v2 path that ranks leaf candidates by squared centre distance
+    (option `uniform`): random clusters with overlaps, coincident centres (exact ties), a negative radius, and a
+    scene that differs from uniform by one radius only (must take the general path)."""
+    import numpy as np
+    ctx = rm.Context(0)
+    rng = np.random.default_rng(77)
+    cases = []
+    for n, r, spread in [(200, 0.3, 2.0), (64, 0.05, 0.6), (300, 0.5, 1.5), (40, -0.2, 1.0)]:
+        c = rng.uniform(-spread, spread, size=(n, 3)).astype(np.float32)
+        c[1] = c[0]                    # coincident centres
+        c[3] = c[2] + np.float32(1e-7)  # and a near tie
+        cases.append(np.concatenate([c, np.full((n, 1), r, np.float32)], axis=1).astype(np.float64))
+    almost = cases[0].copy()
+    almost[17, 3] = np.float64(np.float32(0.3000001))
+    cases.append(almost)
+    for sp in cases:
+        for accel in ("BVH", "None"):
+            outs = []
+            for opts in (dict(kernel=2, uniform=1), dict(kernel=2, uniform=0), dict(kernel=1)):
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                outs.append(gpu_render(rm, ctx, None, accel, 200, 120, (0.2, 0.5), spheres=sp))
+            for o in outs[1:]:
+                assert_same(o, outs[0], "uniform radius variants %s" % accel)
+            assert_same(outs[0], cpu_render(oracle, None, accel, 200, 120, (0.2, 0.5), spheres=sp), "vs oracle")
 
 
 def test_frames_in_flight_on_separate_streams(rm):

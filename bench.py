@@ -12,9 +12,12 @@ main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the r
 (interleaved 16-row stripes) and {RGBA, sdfEval, iters} are gathered to rank 0 and
 reassembled -- total work fixed, so scaling is "strong".
 
-Frames are independent, so `--frames-in-flight S` (default 6) enqueues consecutive frames on S HIP streams with
+Frames are independent, so `--frames-in-flight S` (default 8) enqueues consecutive frames on S HIP streams with
 S buffer sets: the tail of a frame's persistent kernel -- its slowest rays, ~0.3 ms during which most CUs idle --
 overlaps the following frames.  Every frame is still rendered, shaded and reduced in full; S = 1 is strictly serial.
+With frames in flight a launch uses two persistent workgroups per CU instead of four (the other frames' workgroups
+fill the CU) and the process asks the HIP runtime for eight hardware queues (GPU_MAX_HW_QUEUES, default four) so that
+the eight streams do not share queues.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- HBM: 12 B/pixel of mandatory output / render-kernel time (HIP events)
@@ -25,6 +28,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: one hardware queue per stream in flight
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -138,7 +143,7 @@ def main():
                     help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
                          "(main.ts:438-441) and report the per-frame metric series (main.ts:550-566); N = 1 only")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (rm_set_option)")
-    ap.add_argument("--frames-in-flight", type=int, default=6,
+    ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames enqueued concurrently, each on its own HIP stream with its own buffers: the tail of a "
                          "frame's persistent kernel (its slowest rays) overlaps the next frames; 1 = strictly serial")
     args = ap.parse_args()
@@ -194,18 +199,15 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    # With frames in flight a frame's internal balance does not matter (the next frames fill the gaps), so three
-    # quarters of every tile queue are assigned to the waves statically and the queue atomic (a ~10 us device-scope
-    # round trip per 128-pixel item) is paid for the last quarter only.  Alone, a frame is faster with all-dynamic queues.
-    static_share = 75 if (max(1, args.frames_in_flight) > 1 and not args.analytics_sweep and world == 1
-                          and not any(kv.startswith("static=") for kv in args.opt)) else None
-    if static_share is not None:
-        ctx.set_option("static", static_share)
-    # A rank's shard of a sharded frame is small (1/N of the rows): with frames in flight it runs best with half as
-    # many persistent workgroups per launch and all-dynamic queues (scripts/overlap_probe.py: the 1/8-row shard 0.46 ->
-    # 0.34 ms per frame, 1/4 0.62 -> 0.52, 1/2 1.27 -> 1.09).
-    if world > 1 and not any(kv.startswith("blocks_per_cu=") for kv in args.opt):
-        ctx.set_option("blocks_per_cu", 2)
+    # With frames in flight a launch runs best with half as many persistent workgroups (two per CU): the other
+    # frames' workgroups fill the CUs, and each workgroup stages the scene tables once for twice as many tiles.
+    # Whole frame 617 -> 621 frames/s at six streams, 640 at eight streams on eight hardware queues; the 1/8-row
+    # shard of an 8-GPU job 0.46 -> 0.29 ms per frame (scripts/overlap_probe.py, scripts/bench_variants.sh).  The
+    # static tile share (option `static`) lost to this setting and is no longer used here.
+    in_flight_bpc = None
+    if max(1, args.frames_in_flight) > 1 and not args.analytics_sweep and not any(kv.startswith("blocks_per_cu=") for kv in args.opt):
+        in_flight_bpc = 2
+        ctx.set_option("blocks_per_cu", in_flight_bpc)
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
         from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition
@@ -296,12 +298,14 @@ def main():
             asm = D.GpuFrameAssembler(layout, dev, shr.nbuf)
             shr.recv = asm.gather_lists()
 
-        acc = torch.zeros(4, dtype=torch.int64, device=dev)
+        # one accumulator per buffer set: reductions of different frames run concurrently on different streams
+        accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(shr.nbuf)]
+        acc = accs[0]
 
         def assemble(slot):
             with shr.on_stream(slot):
                 frame = asm.assemble(slot)
-                ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), acc)
+                ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), accs[slot])
 
         pending = []
 
@@ -327,6 +331,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up, not a step: every stream's first launch creates its hardware queue and touches its buffer set (tens of
+    # milliseconds each).  With fewer warm-up steps than streams that cost would land in the timed region, so each
+    # stream is used once here; the W warm-up steps follow.
+    if S > args.warmup:
+        for _ in range(S):
+            step(False)
+        finish()
+        sync()
     for _ in range(args.warmup):
         step(False)
     finish()
@@ -360,8 +372,8 @@ def main():
     if S > 1 and world == 1:
         ser = []
         b = sets[0]
-        if static_share is not None:
-            ctx.set_option("static", 0)  # the launch running alone uses the all-dynamic queues
+        if in_flight_bpc is not None:
+            ctx.set_option("blocks_per_cu", 4)  # the launch running alone uses the library default (four per CU)
         with torch.cuda.stream(streams[0]):
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,8 +384,8 @@ def main():
                 ser.append((e0, e1))
                 torch.cuda.synchronize()
         kern_serial_ms = sum(a.elapsed_time(c) for a, c in ser) / len(ser)
-        if static_share is not None:
-            ctx.set_option("static", static_share)
+        if in_flight_bpc is not None:
+            ctx.set_option("blocks_per_cu", in_flight_bpc)
     bytes_per_launch = ALG_BYTES_PER_PIXEL * px_per_launch
     if S > 1:
         achieved = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
@@ -414,9 +426,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/traffic.json"
                          if traffic else None,
-                         "kernel": "render_kernel_v2<2,true>" if args.workload == "C3" else "render kernel",
+                         "kernel": "render_kernel_v2<2,true,true>" if args.workload == "C3" else "render kernel",
                          "kernel_ms": kern_serial_ms, "kernel_ms_in_flight": kern_ms, "frames_in_flight": S,
-                         "static_tile_share_percent": static_share or 0,
+                         "persistent_workgroups_per_cu": in_flight_bpc or 4,
                          "achieved_one_launch_alone": achieved_serial,
                          "basis": ("device level: algorithmic bytes per launch x %d launches / wall time of the timed "
                                    "region (%d frames in flight overlap; kernel_ms is the launch running alone, "

@@ -84,6 +84,7 @@ struct rm_ctx {
     int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
                              // frames overlap (bench.py sets 75 with frames in flight); alone it costs the frame its balance
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
+    int64_t opt_rel = 1;      // v2: BVH node boxes relative to the frame's ray origin, as doubles in LDS (slab test without conversions)
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
@@ -362,6 +363,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     const bool nn_on = ctx->opt_nn == 1 || (ctx->opt_nn == 2 && ctx->host.spheres.size() <= 512);
     p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
     p.leaf_order = ctx->host.leaf_order ? 1 : 0;
+    p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2) {  // one radius, bit for bit
         const auto &sp = ctx->host.spheres;
@@ -919,6 +921,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_uniform = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "rel")) {
+        ctx->opt_rel = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "static")) {
         if (value < 0 || value > 95) return fail(ctx, RM_E_INVALID, "static must be in [0, 95] percent");
         ctx->opt_static = value;
@@ -975,6 +981,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "sub")) *value = ctx->opt_sub;
     else if (!std::strcmp(key, "static")) *value = ctx->opt_static;
     else if (!std::strcmp(key, "uniform")) *value = ctx->opt_uniform;
+    else if (!std::strcmp(key, "rel")) *value = ctx->opt_rel;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

@@ -349,6 +349,41 @@ __device__ __forceinline__ bool slab_inv(const float lo[3], const float hi[3], c
     return true;
 }
 
+// The same test on a node box stored relative to the ray origin: rel = {lo - o, hi - o} as doubles, the very
+// differences `(this.min[i] - ray.origin[i])` the reference forms (boundingBox.ts:84-85), computed once per frame and
+// node when the persistent workgroup stages the scene (the origin is the same for every ray of a frame).  Saves the
+// six conversions and six subtractions of every test.  Parallel axes: o < lo <=> lo - o > 0 and o > hi <=> hi - o < 0
+// exactly (the difference of two distinct binary32 values is a non-zero double).
+__device__ __forceinline__ bool slab_rel(const double *rel, const RayInv &ri, double &tEnter, double &tExit) {
+    if (__ballot(ri.any_par) == 0) {
+        const double ax = rel[0] * ri.inv[0], bx = rel[3] * ri.inv[0];
+        const double ay = rel[1] * ri.inv[1], by = rel[4] * ri.inv[1];
+        const double az = rel[2] * ri.inv[2], bz = rel[5] * ri.inv[2];
+        const double tMin = __builtin_fmax(__builtin_fmax(__builtin_fmin(ax, bx), __builtin_fmin(ay, by)), __builtin_fmin(az, bz));
+        const double tMax = __builtin_fmin(__builtin_fmin(__builtin_fmax(ax, bx), __builtin_fmax(ay, by)), __builtin_fmax(az, bz));
+        tEnter = tMin;
+        tExit = tMax;
+        return !(tMin > tMax);
+    }
+    double tMin = -__builtin_inf(), tMax = __builtin_inf();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (ri.par[a]) {
+            if (rel[a] > 0.0 || rel[a + 3] < 0.0) return false;
+        } else {
+            const double ta = rel[a] * ri.inv[a];
+            const double tb = rel[a + 3] * ri.inv[a];
+            const double t0 = __builtin_fmin(ta, tb), t1 = __builtin_fmax(ta, tb);
+            tMin = __builtin_fmax(tMin, t0);
+            tMax = __builtin_fmin(tMax, t1);
+            if (tMin > tMax) return false;
+        }
+    }
+    tEnter = tMin;
+    tExit = tMax;
+    return true;
+}
+
 struct Interval {
     double tEnter, tExit;
     int ord;  // node index == position in the traversal order of bvh.ts:136-173

@@ -84,6 +84,7 @@ struct SceneView {
     const uint16_t *pq_list;
     const uint32_t *nn_cells;
     const uint16_t *nn_list;
+    const double *rel;  // REL kernels: per BVH node {lo - origin, hi - origin} as doubles (LDS, built per launch)
     int n_prims, bvh_nodes;
 };
 
@@ -512,6 +513,14 @@ struct RayList {
 
 // BVH.onRayMarchStart (bvh.ts:181-202): one traversal; records hit leaves, returns the first
 // interval in sorted order (min tEnter, ties: first in traversal order)
+template <bool REL>
+__device__ __forceinline__ bool node_slab(const SceneView &S, const RmBvhNode &node, int i, const Ray &r, const RayInv &ri,
+                                          double &tE, double &tX) {
+    if (REL) return slab_rel(S.rel + 6 * i, ri, tE, tX);
+    return slab_inv(node.lo, node.hi, r, ri, tE, tX);
+}
+
+template <bool REL>
 __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri, RayList &L, Interval &first) {
     bool have = false;
     int i = 0;
@@ -521,7 +530,7 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
         RM_CNT(5)
         const RmBvhNode node = S.nodes[i];
         double tE, tX;
-        if (!slab_inv(node.lo, node.hi, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
+        if (!node_slab<REL>(S, node, i, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {  // bvh.ts:145,151
             i = node.skip;
             continue;
         }
@@ -548,6 +557,7 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
 }
 
 // successor of key (keyT, keyOrd) in the stable-sorted interval order of bvh.ts:176
+template <bool REL>
 __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, RayList &L, double keyT, int keyOrd,
                          Interval &out) {
     bool have = false;
@@ -563,7 +573,7 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, Ray
             const int id = L.col[e * 64];
             const RmBvhNode node = S.nodes[id];
             double tE, tX;
-            slab_inv(node.lo, node.hi, r, ri, tE, tX);  // hit by construction; same arithmetic, same values
+            node_slab<REL>(S, node, id, r, ri, tE, tX);  // hit by construction; same arithmetic, same values
             const double cE = __builtin_fmax(tE, 0.0);
             const double cX = __builtin_fmin(tX, RM_MAX_DIST);
             const bool after = cE > keyT || (cE == keyT && id > keyOrd);
@@ -587,7 +597,7 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, Ray
     while (i < n) {
         const RmBvhNode node = S.nodes[i];
         double tE, tX;
-        if (!slab_inv(node.lo, node.hi, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {
+        if (!node_slab<REL>(S, node, i, r, ri, tE, tX) || tX < 0.0 || tE > RM_MAX_DIST) {
             i = node.skip;
             continue;
         }
@@ -683,7 +693,7 @@ __device__ __forceinline__ RmRenderParams cold_params() {
 #endif
 }
 
-template <int ACCEL, bool LDS, bool UR = false>
+template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -699,6 +709,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
     S.pq_list = P.pq_list;
     S.nn_cells = P.nn_cells;
     S.nn_list = P.nn_list;
+    S.rel = nullptr;
     S.n_prims = P.n_prims;
     S.bvh_nodes = P.bvh_nodes;
     const bool use_grid = ACCEL == 2 && P.use_grid != 0;
@@ -718,6 +729,16 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
         S.spheres = stage(smem, off, P.spheres, P.n_prims);
         S.radii = stage(smem, off, P.radii, P.n_prims);
         off = (off + 15) & ~static_cast<size_t>(15);
+        if (REL) {  // node boxes relative to this frame's ray origin (slab_rel)
+            double *rel = reinterpret_cast<double *>(smem + off);
+            for (int k = threadIdx.x; k < P.bvh_nodes * 6; k += blockDim.x) {
+                const int node = k / 6, c = k - node * 6;
+                const float v = c < 3 ? P.bvh[node].lo[c] : P.bvh[node].hi[c - 3];
+                rel[k] = static_cast<double>(v) - P.origin_d[c < 3 ? c : c - 3];
+            }
+            S.rel = rel;
+            off += static_cast<size_t>(P.bvh_nodes) * 48;
+        }
         __syncthreads();
     }
     RayList L;
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
 #ifdef RM_STAMPS
                             const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
 #endif
-                            haveCur = bvh_prologue(S, ray, ri, L, cur);
+                            haveCur = bvh_prologue<REL>(S, ray, ri, L, cur);
 #ifdef RM_STAMPS
                             t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
                             t_prev_ += __builtin_amdgcn_s_memtime() - t_pr0;
@@ -880,7 +901,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams 
                         if (t < cur.tEnter) skip = cur.tEnter - t;
                         else if (t > cur.tExit) {
                             const Interval prev = cur;
-                            haveCur = bvh_next(S, ray, ri, L, prev.tEnter, prev.ord, cur);
+                            haveCur = bvh_next<REL>(S, ray, ri, L, prev.tEnter, prev.ord, cur);
                             if (!haveCur) terminate = true;
                             else if (cur.tEnter > t) skip = cur.tEnter - t;
                         }
@@ -1028,17 +1049,33 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     if (p.list_cap < 1) p.list_cap = 1;
     if (p.refill_threshold < 1) p.refill_threshold = 1;
     if (p.refill_threshold > 64) p.refill_threshold = 64;
-    const size_t list_bytes = p.accel == 2 ? static_cast<size_t>(4) * p.list_cap * 128 : 0;
+    size_t list_bytes = p.accel == 2 ? static_cast<size_t>(4) * p.list_cap * 128 : 0;
     const size_t scene_bytes = scene_lds_bytes(p);
     // stage the scene in LDS when it leaves room for >= 2 workgroups per CU (160 KB LDS)
     const bool lds = p.nodes_in_lds != 0 && scene_bytes + list_bytes + 16 <= 64 * 1024;
-    const size_t shmem = (lds ? scene_bytes : 0) + list_bytes + 16;
+    // Origin-relative node boxes (48 B per node) ride along when everything still fits four workgroups per CU
+    // (40 KB each: the occupancy the register budget allows); the per-ray hit lists give way down to 16 entries
+    // (rays that hit more leaves take the tree-walk form of bvh_next, as they do beyond any cap).
+    bool rel = false;
+    const size_t rel_bytes = static_cast<size_t>(p.bvh_nodes) * 48;
+    if (lds && p.accel == 2 && p.rel_boxes) {
+        int cap = p.list_cap;
+        while (cap > 16 && scene_bytes + rel_bytes + static_cast<size_t>(4) * cap * 128 + 32 > 40 * 1024) cap -= 8;
+        if (scene_bytes + rel_bytes + static_cast<size_t>(4) * cap * 128 + 32 <= 40 * 1024) {
+            rel = true;
+            p.list_cap = cap;
+            list_bytes = static_cast<size_t>(4) * cap * 128;
+        }
+    }
+    const size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
     hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(blocks), block(256);
 #define RM_V2(A, L) hipLaunchKernelGGL((render_kernel_v2<A, L>), grid, block, shmem, stream, p)
     if (p.accel == 2) {
-        if (lds && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true>), grid, block, shmem, stream, p);
+        if (lds && rel && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true, true>), grid, block, shmem, stream, p);
+        else if (lds && rel) hipLaunchKernelGGL((render_kernel_v2<2, true, false, true>), grid, block, shmem, stream, p);
+        else if (lds && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true>), grid, block, shmem, stream, p);
         else if (lds) RM_V2(2, true);
         else RM_V2(2, false);
     }

@@ -127,7 +127,7 @@ struct RmRenderParams {
     int32_t local_rows;        // packed rows this launch renders (= y_end - y_start without striping)
     int32_t stripe_rows;       // > 0: rows are dealt in stripes of this many rows, round-robin over n_parts;
     int32_t n_parts, part;     //      this launch renders the stripes of `part`, packed in increasing y
-    int32_t reserved1;
+    int32_t rel_boxes;         // v2: stage origin-relative node boxes (doubles) in LDS when they fit (option `rel`)
     unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch
     unsigned long long *stamps;   // diagnostic build (-DRM_STAMPS) only: 8 cycle accumulators
     const uint32_t *pq_cells;

@@ -12,12 +12,12 @@ main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the r
 (interleaved 16-row stripes) and {RGBA, sdfEval, iters} are gathered to rank 0 and
 reassembled -- total work fixed, so scaling is "strong".
 
-Frames are independent, so `--frames-in-flight S` (default 8) enqueues consecutive frames on S HIP streams with
+Frames are independent, so `--frames-in-flight S` (default 12) enqueues consecutive frames on S HIP streams with
 S buffer sets: the tail of a frame's persistent kernel -- its slowest rays, ~0.3 ms during which most CUs idle --
 overlaps the following frames.  Every frame is still rendered, shaded and reduced in full; S = 1 is strictly serial.
 With frames in flight a launch uses two persistent workgroups per CU instead of four (the other frames' workgroups
-fill the CU) and the process asks the HIP runtime for eight hardware queues (GPU_MAX_HW_QUEUES, default four) so that
-the eight streams do not share queues.
+fill the CU) and the process asks the HIP runtime for sixteen hardware queues (GPU_MAX_HW_QUEUES, default four) so
+that the streams do not share queues.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- HBM: 12 B/pixel of mandatory output / render-kernel time (HIP events)
@@ -29,7 +29,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: one hardware queue per stream in flight
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts: a hardware queue per stream in flight (default 4)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -143,7 +143,7 @@ def main():
                     help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
                          "(main.ts:438-441) and report the per-frame metric series (main.ts:550-566); N = 1 only")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (rm_set_option)")
-    ap.add_argument("--frames-in-flight", type=int, default=8,
+    ap.add_argument("--frames-in-flight", type=int, default=12,
                     help="frames enqueued concurrently, each on its own HIP stream with its own buffers: the tail of a "
                          "frame's persistent kernel (its slowest rays) overlaps the next frames; 1 = strictly serial")
     args = ap.parse_args()

@@ -78,7 +78,8 @@ struct rm_ctx {
     int64_t opt_grid = 1;
     int64_t opt_nn = 2;  // per-cell nearest-candidate lists for the all-primitive fallback: 0 off, 1 on, 2 auto (scenes of
                          // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
-    int64_t opt_blocks_per_cu = 4;
+    int64_t opt_blocks_per_cu = 4;  // persistent workgroups per launch and CU (a frame alone: 4 beats 5, 2.02 against 2.07 ms)
+    int64_t opt_lds_kb = 32;        // v2: LDS budget per workgroup the launcher trims the hit lists to (32: five per CU, 40: four)
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
     int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
@@ -364,6 +365,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
     p.leaf_order = ctx->host.leaf_order ? 1 : 0;
     p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
+    p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2) {  // one radius, bit for bit
         const auto &sp = ctx->host.spheres;
@@ -921,6 +923,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_uniform = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "lds_kb")) {
+        if (value < 16 || value > 64) return fail(ctx, RM_E_INVALID, "lds_kb must be in [16, 64]");
+        ctx->opt_lds_kb = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "rel")) {
         ctx->opt_rel = value ? 1 : 0;
         return RM_OK;
@@ -982,6 +989,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "static")) *value = ctx->opt_static;
     else if (!std::strcmp(key, "uniform")) *value = ctx->opt_uniform;
     else if (!std::strcmp(key, "rel")) *value = ctx->opt_rel;
+    else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

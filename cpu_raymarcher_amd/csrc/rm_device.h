@@ -489,6 +489,42 @@ __device__ __forceinline__ Vec3f point_at(const Ray &r, double t) {
     return p;
 }
 
+// PhongModel.shade for one pixel (phongModel.ts:33-72).  A real function, not inlined: the device library's pow keeps
+// ~18 double constants in VGPRs, and inlined into the render kernels they were hoisted out of the wave loop and held
+// for the whole kernel (36 of its 128 VGPRs), whichever shader the frame used.
+__device__ __attribute__((noinline)) static uchar4 shade_phong(uint8_t depth, uint8_t n0, uint8_t n1, uint8_t n2, double l0,
+                                                                double l1, double l2) {
+    if (depth >= 255) return make_uchar4(10, 10, 20, 255);
+    float nx = to_f32(static_cast<double>(n0) / 127.5 - 1.0);
+    float ny = to_f32(static_cast<double>(n1) / 127.5 - 1.0);
+    float nz = to_f32(static_cast<double>(n2) / 127.5 - 1.0);
+    double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
+    if (len > 0) len = 1 / __builtin_sqrt(len);
+    nx = to_f32(nx * len);
+    ny = to_f32(ny * len);
+    nz = to_f32(nz * len);
+    const double ndl = static_cast<double>(nx) * l0 + static_cast<double>(ny) * l1 +
+                       static_cast<double>(nz) * l2;
+    const double diffuse = ndl > 0.0 ? ndl : 0.0;
+    const double k2 = 2 * ndl;
+    float rx = to_f32(nx * k2), ry = to_f32(ny * k2), rz = to_f32(nz * k2);
+    rx = to_f32(static_cast<double>(rx) - l0);
+    ry = to_f32(static_cast<double>(ry) - l1);
+    rz = to_f32(static_cast<double>(rz) - l2);
+    double rl = static_cast<double>(rx) * rx + static_cast<double>(ry) * ry + static_cast<double>(rz) * rz;
+    if (rl > 0) rl = 1 / __builtin_sqrt(rl);
+    rz = to_f32(rz * rl);
+    const double vdr = static_cast<double>(rz);  // dot((0,0,1), reflect)
+    const double base = vdr > 0.0 ? vdr : 0.0;
+    // Math.pow is not correctly rounded on either side; the byte is within 1 LSB
+    const double spec = 0.5 * pow(base, 32.0);
+    double inten = 0.1 + diffuse + spec;
+    inten = inten < 1.0 ? inten : 1.0;
+    const double color = 255 * inten * (1 - static_cast<double>(depth) / 255);
+    const uint8_t c = u8clamp(color);
+    return make_uchar4(c, c, c, 255);
+}
+
 // ShadingModel.shade for one pixel.  Heatmaps (SDFHeatmap.ts:24-29, IterationHeatmap.ts:24-29)
 // and Normal (normalModel.ts:21-24) are pure integer; Phong follows phongModel.ts:33-72 in
 // double with f32 stores.
@@ -501,37 +537,7 @@ __device__ __forceinline__ uchar4 shade_pixel(int shader, uint8_t depth, uint8_t
         const uint32_t g = 512u - 2u * k < 255u ? 512u - 2u * k : 255u;  // Math.min(-2k + 512, 255)
         return make_uchar4(static_cast<uint8_t>(r), static_cast<uint8_t>(g), 0, 255);
     }
-    if (shader == 1) {
-        if (depth >= 255) return make_uchar4(10, 10, 20, 255);
-        float nx = to_f32(static_cast<double>(n0) / 127.5 - 1.0);
-        float ny = to_f32(static_cast<double>(n1) / 127.5 - 1.0);
-        float nz = to_f32(static_cast<double>(n2) / 127.5 - 1.0);
-        double len = static_cast<double>(nx) * nx + static_cast<double>(ny) * ny + static_cast<double>(nz) * nz;
-        if (len > 0) len = 1 / __builtin_sqrt(len);
-        nx = to_f32(nx * len);
-        ny = to_f32(ny * len);
-        nz = to_f32(nz * len);
-        const double ndl = static_cast<double>(nx) * light[0] + static_cast<double>(ny) * light[1] +
-                           static_cast<double>(nz) * light[2];
-        const double diffuse = ndl > 0.0 ? ndl : 0.0;
-        const double k2 = 2 * ndl;
-        float rx = to_f32(nx * k2), ry = to_f32(ny * k2), rz = to_f32(nz * k2);
-        rx = to_f32(static_cast<double>(rx) - light[0]);
-        ry = to_f32(static_cast<double>(ry) - light[1]);
-        rz = to_f32(static_cast<double>(rz) - light[2]);
-        double rl = static_cast<double>(rx) * rx + static_cast<double>(ry) * ry + static_cast<double>(rz) * rz;
-        if (rl > 0) rl = 1 / __builtin_sqrt(rl);
-        rz = to_f32(rz * rl);
-        const double vdr = static_cast<double>(rz);  // dot((0,0,1), reflect)
-        const double base = vdr > 0.0 ? vdr : 0.0;
-        // Math.pow is not correctly rounded on either side; the byte is within 1 LSB
-        const double spec = 0.5 * pow(base, 32.0);
-        double inten = 0.1 + diffuse + spec;
-        inten = inten < 1.0 ? inten : 1.0;
-        const double color = 255 * inten * (1 - static_cast<double>(depth) / 255);
-        const uint8_t c = u8clamp(color);
-        return make_uchar4(c, c, c, 255);
-    }
+    if (shader == 1) return shade_phong(depth, n0, n1, n2, light[0], light[1], light[2]);
     return make_uchar4(n0, n1, n2, 255);
 }
 

@@ -694,7 +694,8 @@ __device__ __forceinline__ RmRenderParams cold_params() {
 }
 
 template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
-__global__ __launch_bounds__(256, 4) void render_kernel_v2(const RmRenderParams P) {
+// 96 VGPRs without spills (since the Phong pow left the kernel): five waves per SIMD when the LDS footprint allows
+__global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -1032,9 +1033,43 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     p.tiles_y = tiles_y;
     p.tiles_x_magic = tiles_x == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / static_cast<unsigned long long>(tiles_x)) + 1u;  // 0: k / 1
     const unsigned needed = static_cast<unsigned>((static_cast<long long>(tiles_x) * tiles_y + 3) / 4);  // 4 waves each
-    const unsigned resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) *
-                              static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
-    const unsigned blocks = needed < resident ? (needed ? needed : 1u) : resident;
+    unsigned resident = 0, blocks = 0;  // set below, once the LDS footprint (workgroups per CU) is known
+    if (p.list_cap < 1) p.list_cap = 1;
+    if (p.refill_threshold < 1) p.refill_threshold = 1;
+    if (p.refill_threshold > 64) p.refill_threshold = 64;
+    size_t list_bytes = p.accel == 2 ? static_cast<size_t>(4) * p.list_cap * 128 : 0;
+    const size_t scene_bytes = scene_lds_bytes(p);
+    // stage the scene in LDS when it leaves room for >= 2 workgroups per CU (160 KB LDS)
+    const bool lds = p.nodes_in_lds != 0 && scene_bytes + list_bytes + 16 <= 64 * 1024;
+    // LDS budget per workgroup: 32 KB lets five workgroups (five waves per SIMD, what 96 VGPRs allow) share a CU's
+    // 160 KB, 40 KB four.  The per-ray hit lists give way down to 16 entries to reach a budget (rays that hit more
+    // leaves take the tree-walk form of bvh_next, as they do beyond any cap); origin-relative node boxes (48 B per
+    // node) ride along when they fit the same budget.
+    bool rel = false;
+    const size_t rel_bytes = static_cast<size_t>(p.bvh_nodes) * 48;
+    if (lds && p.accel == 2) {
+        auto fits = [&](size_t extra, int cap, size_t budget) { return scene_bytes + extra + static_cast<size_t>(4) * cap * 128 + 32 <= budget; };
+        auto trim = [&](size_t extra, size_t budget) {  // largest cap <= list_cap (>= 16, or list_cap itself if smaller) that fits; 0 if none
+            int cap = p.list_cap;
+            while (cap > 16 && !fits(extra, cap, budget)) cap -= 8;
+            return fits(extra, cap, budget) ? cap : 0;
+        };
+        const size_t budgets[2] = {static_cast<size_t>(p.lds_budget_kb > 0 ? p.lds_budget_kb : 32) * 1024, 40 * 1024};
+        for (int b = 0; b < 2; ++b) {
+            int cap = p.rel_boxes ? trim(rel_bytes + 16, budgets[b]) : 0;
+            if (cap > 0) rel = true;
+            else cap = trim(0, budgets[b]);
+            if (cap > 0) {
+                p.list_cap = cap;
+                list_bytes = static_cast<size_t>(4) * cap * 128;
+                break;
+            }
+            rel = false;
+        }
+    }
+    const size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
+    resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) * static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
+    blocks = needed < resident ? (needed ? needed : 1u) : resident;
     // static share: three quarters of the shortest queue, in whole rounds over all waves
     p.total_waves = static_cast<int32_t>(blocks * 4);
     p.static_per_wave = 0;
@@ -1046,28 +1081,6 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
         p.static_per_wave = static_cast<int32_t>(rounds);
         p.queue_base = static_cast<int32_t>(rounds * per_round);
     }
-    if (p.list_cap < 1) p.list_cap = 1;
-    if (p.refill_threshold < 1) p.refill_threshold = 1;
-    if (p.refill_threshold > 64) p.refill_threshold = 64;
-    size_t list_bytes = p.accel == 2 ? static_cast<size_t>(4) * p.list_cap * 128 : 0;
-    const size_t scene_bytes = scene_lds_bytes(p);
-    // stage the scene in LDS when it leaves room for >= 2 workgroups per CU (160 KB LDS)
-    const bool lds = p.nodes_in_lds != 0 && scene_bytes + list_bytes + 16 <= 64 * 1024;
-    // Origin-relative node boxes (48 B per node) ride along when everything still fits four workgroups per CU
-    // (40 KB each: the occupancy the register budget allows); the per-ray hit lists give way down to 16 entries
-    // (rays that hit more leaves take the tree-walk form of bvh_next, as they do beyond any cap).
-    bool rel = false;
-    const size_t rel_bytes = static_cast<size_t>(p.bvh_nodes) * 48;
-    if (lds && p.accel == 2 && p.rel_boxes) {
-        int cap = p.list_cap;
-        while (cap > 16 && scene_bytes + rel_bytes + static_cast<size_t>(4) * cap * 128 + 32 > 40 * 1024) cap -= 8;
-        if (scene_bytes + rel_bytes + static_cast<size_t>(4) * cap * 128 + 32 <= 40 * 1024) {
-            rel = true;
-            p.list_cap = cap;
-            list_bytes = static_cast<size_t>(4) * cap * 128;
-        }
-    }
-    const size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
     hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(blocks), block(256);

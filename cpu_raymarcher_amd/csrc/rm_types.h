@@ -142,6 +142,7 @@ struct RmRenderParams {
     // v2: the first `static_per_wave` items of every wave are assigned without an atomic (wave g takes entries
     // g + total_waves * j of the interleaved queues); the queues hand out the rest, starting at queue_base
     int32_t static_per_wave, queue_base, total_waves;
+    int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = 32 KB: five workgroups per CU)
     int32_t static_share;  // percent of the shortest queue assigned statically (option; 0 = all dynamic)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box

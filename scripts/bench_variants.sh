@@ -1,14 +1,14 @@
-run() { echo -n "$* : "; env $ENVV timeout -k 10 200 python bench.py --steps 60 --warmup 8 "$@" 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" || exit 1; }
-ENVV="A=1"
+#!/bin/bash
+# bench.py under different in-flight settings (frames/s, ms per step, launch alone).  usage: bash scripts/bench_variants.sh
+run() { echo -n "Q=${GPU_MAX_HW_QUEUES:-default(8 in bench.py)} $* : "; timeout -k 10 200 python bench.py --steps 96 --warmup 16 "$@" 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],4), round(d['roofline']['kernel_ms'],3))" || exit 1; }
 run
-run --opt static=0 --opt blocks_per_cu=2
-run --opt static=0 --opt blocks_per_cu=2 --frames-in-flight 8
-run --opt static=75 --opt blocks_per_cu=2 --frames-in-flight 8
-run --opt static=0 --opt blocks_per_cu=3 --frames-in-flight 8
-run --frames-in-flight 8
-ENVV="GPU_MAX_HW_QUEUES=8"
-echo "GPU_MAX_HW_QUEUES=8"
-run --frames-in-flight 8
-run --opt static=0 --opt blocks_per_cu=2 --frames-in-flight 8
-run --opt static=0 --opt blocks_per_cu=2 --frames-in-flight 12
+run --frames-in-flight 12
+run --frames-in-flight 16
+export GPU_MAX_HW_QUEUES=12
+run --frames-in-flight 12
+export GPU_MAX_HW_QUEUES=16
+run --frames-in-flight 16
+run --frames-in-flight 12
+export GPU_MAX_HW_QUEUES=4
+run --frames-in-flight 12

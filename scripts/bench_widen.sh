@@ -4,7 +4,7 @@
 set -e
 WL=${@:-N3 N3mixed N4chicken N4screw N4mandelbulb}
 for w in $WL; do
-  timeout -k 10 200 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/widen_$w.json 2> gpurun_out/widen_$w.err
+  timeout -k 10 200 python bench.py --workload $w --steps 24 --warmup 2 > gpurun_out/widen_$w.json 2> gpurun_out/widen_$w.err
   python - "$w" <<'PY'
 import json, sys
 d = json.load(open('gpurun_out/widen_%s.json' % sys.argv[1]))

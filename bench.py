@@ -9,8 +9,9 @@ A step = one frame of BASELINE.json's metric workload (C3: Dense Sphere Grid, 12
 3840x2160, sphere tracing + BVH, iteration-heatmap shader): render + fused shade into
 {depth, normal, sdfEval, iters, RGBA} resident in HBM, then the diagnostics reduction of
 main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the ranks
-(interleaved 16-row stripes) and {RGBA, sdfEval, iters} are gathered to rank 0 and
-reassembled -- total work fixed, so scaling is "strong".
+(interleaved 16-row stripes); every rank reduces the counters of its own rows, and one gather
+brings its RGBA rows and its 32-byte partial diagnostics to rank 0, which reassembles the frame
+and combines the partial sums -- total work fixed, so scaling is "strong".
 
 Frames are independent, so `--frames-in-flight S` (default 12) enqueues consecutive frames on S HIP streams with
 S buffer sets: the tail of a frame's persistent kernel -- its slowest rays, ~0.3 ms during which most CUs idle --
@@ -205,9 +206,18 @@ def main():
     # shard of an 8-GPU job 0.46 -> 0.29 ms per frame (scripts/overlap_probe.py, scripts/bench_variants.sh).  The
     # static tile share (option `static`) lost to this setting and is no longer used here.
     in_flight_bpc = None
-    if max(1, args.frames_in_flight) > 1 and not args.analytics_sweep and not any(kv.startswith("blocks_per_cu=") for kv in args.opt):
-        in_flight_bpc = 2
-        ctx.set_option("blocks_per_cu", in_flight_bpc)
+    in_flight_opts = {}  # option -> (value with frames in flight, library default restored for the launch measured alone)
+    if max(1, args.frames_in_flight) > 1 and not args.analytics_sweep:
+        in_flight_opts["blocks_per_cu"] = (2, 4)
+        if world == 1:  # whole frames: 256-pixel work items of 8 x 32 pixels (744 -> 763 frames/s; alone 2.00 -> 2.24 ms)
+            in_flight_opts["item_px"] = (256, 128)
+            in_flight_opts["tile_w"] = (8, 16)
+        for k in list(in_flight_opts):
+            if any(kv.startswith(k + "=") for kv in args.opt):
+                del in_flight_opts[k]
+        for k, (v, _) in in_flight_opts.items():
+            ctx.set_option(k, v)
+        in_flight_bpc = in_flight_opts.get("blocks_per_cu", (None, None))[0]
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
         from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition
@@ -263,9 +273,24 @@ def main():
         def finish():
             pass
     else:
-        layout = D.FrameLayout(W, H, world, ("rgba", "sdf", "iters"), args.partition, args.stripe)
+        # Only RGBA travels (north_star: "RCCL gather ... of the per-tile RGBA buffers").  The per-pixel counters stay on
+        # the rank that produced them: each rank reduces its own rows (main.ts:528-548 is a sum / max / min, so partial
+        # results combine exactly) into a 32-byte accumulator in the tail of its packed buffer, which rides along in the
+        # same gather; rank 0 combines the N partial accumulators per frame.
+        gather_counters = args.partition != "interleaved"  # the per-range fallback path keeps the three-section gather
+        sections = ("rgba", "sdf", "iters") if gather_counters else ("rgba",)
+        layout = D.FrameLayout(W, H, world, sections, args.partition, args.stripe, tail=0 if gather_counters else 32)
         render_rows = D.gpu_render_rows(ctx, scene, W, H, wl["shader"], layout)
         timed_flag = [False]
+        my_px = W * sum(b - a for a, b in layout.rows(rank))
+        local_counters = {}  # packed buffer -> this rank's sdfEval / iters for that buffer set
+
+        def extra(packed):
+            key = packed.data_ptr()
+            if key not in local_counters:
+                local_counters[key] = {"sdf": torch.zeros(layout.cap * W, dtype=torch.int16, device=dev),
+                                       "iters": torch.zeros(layout.cap * W, dtype=torch.int16, device=dev)}
+            return local_counters[key]
 
         def timed_render_rows(a, b, local, packed):
             if timed_flag[0]:
@@ -277,7 +302,7 @@ def main():
             else:
                 render_rows(a, b, local, packed)
 
-        render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank)
+        render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank, extra=None if gather_counters else extra)
 
         def timed_render_all(packed):
             if timed_flag[0]:
@@ -288,6 +313,10 @@ def main():
                 ev_pairs.append((e0, e1))
             else:
                 render_all(packed)
+            if not gather_counters:  # this rank's partial diagnostics, into the tail that travels with the gather
+                c = extra(packed)
+                tail = packed[layout.tail_offset:layout.tail_offset + 32].view(torch.int64)
+                ctx.reduce_counters_enqueue(c["sdf"][:my_px], c["iters"][:my_px], tail)
 
         shr = D.ShardedFrameRenderer(layout, rank, world, timed_render_rows, u8, coll,
                                      render_all=timed_render_all if render_all else None,
@@ -301,11 +330,17 @@ def main():
         # one accumulator per buffer set: reductions of different frames run concurrently on different streams
         accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(shr.nbuf)]
         acc = accs[0]
+        lo32 = torch.tensor(0xFFFFFFFF, dtype=torch.int64, device=dev)
 
         def assemble(slot):
             with shr.on_stream(slot):
                 frame = asm.assemble(slot)
-                ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), accs[slot])
+                if gather_counters:
+                    ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), accs[slot])
+                else:  # combine the ranks' partial accumulators: sums, max of the low word, min of the high word
+                    part = asm.recv2d[slot][:, layout.tail_offset:layout.tail_offset + 32].view(torch.int64)
+                    torch.sum(part[:, :2], dim=0, out=accs[slot][:2])
+                    accs[slot][2] = torch.amax(part[:, 2] & lo32) | (torch.amin(part[:, 2] >> 32) << 32)
 
         pending = []
 
@@ -372,8 +407,8 @@ def main():
     if S > 1 and world == 1:
         ser = []
         b = sets[0]
-        if in_flight_bpc is not None:
-            ctx.set_option("blocks_per_cu", 4)  # the launch running alone uses the library default (four per CU)
+        for k, (_, dflt) in in_flight_opts.items():
+            ctx.set_option(k, dflt)  # the launch running alone uses the library defaults
         with torch.cuda.stream(streams[0]):
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,8 +419,8 @@ def main():
                 ser.append((e0, e1))
                 torch.cuda.synchronize()
         kern_serial_ms = sum(a.elapsed_time(c) for a, c in ser) / len(ser)
-        if in_flight_bpc is not None:
-            ctx.set_option("blocks_per_cu", in_flight_bpc)
+        for k, (v, _) in in_flight_opts.items():
+            ctx.set_option(k, v)
     bytes_per_launch = ALG_BYTES_PER_PIXEL * px_per_launch
     if S > 1:
         achieved = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
@@ -417,7 +452,7 @@ def main():
             "config": {"workload": wl["name"], "width": W, "height": H, "acceleration_structure": wl["accel"],
                        "shader": wl["shader"], "camera": {"pitch": 0.0, "yaw": 0.0}, "frames_in_flight": S,
                        "parallelism": "1 GPU" if world == 1 else
-                       "row-tile shard x%d (%s, stripe %d) + RCCL gather of RGBA+sdfEval+iters to rank 0"
+                       "row-tile shard x%d (%s, stripe %d) + RCCL gather of RGBA and per-rank diagnostics sums to rank 0"
                        % (world, args.partition, args.stripe)},
             "avg_sdf_calls_per_pixel": d["total_sdf"] / (W * H), "avg_iterations_per_pixel": d["total_iters"] / (W * H),
             "max_sdf_calls": d["max_sdf"], "min_sdf_calls": d["min_sdf"],
@@ -426,9 +461,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/traffic.json"
                          if traffic else None,
-                         "kernel": "render_kernel_v2<2,true,true>" if args.workload == "C3" else "render kernel",
+                         "kernel": "render_kernel_v2<2,true,true,true>" if args.workload == "C3" else "render kernel",
                          "kernel_ms": kern_serial_ms, "kernel_ms_in_flight": kern_ms, "frames_in_flight": S,
                          "persistent_workgroups_per_cu": in_flight_bpc or 4,
+                         "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},
                          "achieved_one_launch_alone": achieved_serial,
                          "basis": ("device level: algorithmic bytes per launch x %d launches / wall time of the timed "
                                    "region (%d frames in flight overlap; kernel_ms is the launch running alone, "
@@ -444,8 +480,11 @@ def main():
             full = {"rgba": u8(4 * W * H), "sdf": u8(2 * W * H), "iters": u8(2 * W * H)}
             tracer.runRaymarcher(scene, None, None, full["sdf"].view(torch.int16), full["iters"].view(torch.int16),
                                  W, H, 0.0, shadedBuffer=full["rgba"], shader=wl["shader"])
+            whole = torch.zeros(4, dtype=torch.int64, device=dev)
+            ctx.reduce_counters_enqueue(full["sdf"].view(torch.int16), full["iters"].view(torch.int16), whole)
             torch.cuda.synchronize()
-            out["gathered_frame_equals_single_gpu_frame"] = all(bool(torch.equal(asm.frame[s], full[s])) for s in full)
+            out["gathered_frame_equals_single_gpu_frame"] = all(bool(torch.equal(asm.frame[s], full[s])) for s in asm.frame)
+            out["combined_diagnostics_equal_single_gpu_diagnostics"] = ctx.decode_acc(whole) == d
         if world == 1 and args.analytics_sweep:
             out["config"]["camera"] = {"pitch": 0.0, "yaw": "+0.015 rad per frame (analytics sweep)"}
             out["analytics_series"] = [

@@ -45,7 +45,9 @@ class FrameLayout:
     """Packed per-rank byte buffer: sections [rgba | sdf | iters | depth | normal], each sized for
     `cap` rows (the largest share of any rank, so every rank sends the same byte count)."""
 
-    def __init__(self, width, height, world, sections=("rgba", "sdf", "iters"), mode="interleaved", stripe=16):
+    def __init__(self, width, height, world, sections=("rgba", "sdf", "iters"), mode="interleaved", stripe=16, tail=0):
+        """tail: extra bytes after the sections (rounded up to 256) that travel with the gather, e.g. the 32-byte
+        diagnostics accumulator of this rank's rows (tail_offset)."""
         self.width, self.height, self.world = width, height, world
         self.sections, self.mode, self.stripe = tuple(sections), mode, stripe
         self.cap = max_local_rows(height, world, mode, stripe)
@@ -54,7 +56,8 @@ class FrameLayout:
         for s in self.sections:
             self.offsets[s] = off
             off += (SECTION_BYTES[s] * width * self.cap + 255) // 256 * 256
-        self.nbytes = max(off, 256)
+        self.tail_offset = off
+        self.nbytes = max(off + (int(tail) + 255) // 256 * 256, 256)
 
     def rows(self, rank):
         return owned_rows(self.height, self.world, rank, self.mode, self.stripe)
@@ -180,9 +183,10 @@ def gpu_render_rows(ctx, scene, width, height, shader, layout):
     return render_rows
 
 
-def gpu_render_all(ctx, scene, width, height, shader, layout, rank):
+def gpu_render_all(ctx, scene, width, height, shader, layout, rank, extra=None):
     """render_all callback for the GPU and the interleaved partition: ONE rm_render_stripes_device
-    launch writes every stripe of this rank into the packed buffer."""
+    launch writes every stripe of this rank into the packed buffer.  extra(packed) -> dict name -> device buffer for
+    outputs that are not sections of the layout (rank-local sdfEval / iters when only RGBA is gathered)."""
     from . import _native as N
     from .host import _job
     if layout.mode != "interleaved":
@@ -191,8 +195,10 @@ def gpu_render_all(ctx, scene, width, height, shader, layout, rank):
     want = set(layout.sections)
 
     def render_all(packed):
+        local = extra(packed) if extra else {}
+
         def sec(name):
-            return layout.section(packed, name) if name in want else None
+            return layout.section(packed, name) if name in want else local.get(name)
         job = _job(scene, width, height, 0.0, 0, height, "sphere-tracer")
         ctx.render_stripes(job, layout.stripe, layout.world, rank, sec("depth"), sec("normal"), sec("sdf"),
                            sec("iters"), rgba=sec("rgba"), shader=sh)

@@ -45,3 +45,22 @@ def test_row_partitions_cover_the_frame(rm):
                 assert all(sum(b - a for a, b in D.owned_rows(H, world, r, mode, 16)) <= cap for r in range(world))
     # the reference's contiguous rule (main.ts:444-449)
     assert D.owned_rows(2160, 8, 7, "contiguous") == [(1890, 2160)]
+
+
+def test_layout_tail_travels_after_the_sections(rm):
+    """bench.py gathers RGBA only and lets every rank's 32-byte diagnostics accumulator ride in the tail of its
+    packed buffer: the tail must not overlap a section and the partial accumulators must combine exactly."""
+    import numpy as np
+    from cpu_raymarcher_amd import distributed as D
+    plain = D.FrameLayout(3840, 2160, 8, ("rgba",), "interleaved", 16)
+    tailed = D.FrameLayout(3840, 2160, 8, ("rgba",), "interleaved", 16, tail=32)
+    assert tailed.offsets == plain.offsets and tailed.tail_offset == plain.nbytes
+    assert tailed.nbytes == plain.nbytes + 256 and tailed.tail_offset % 256 == 0
+    buf = np.zeros(tailed.nbytes, np.uint8)
+    assert tailed.section(buf, "rgba").size == 4 * 3840 * tailed.cap <= tailed.tail_offset
+    # sum / max / min of per-rank partial accumulators = the accumulator of the whole frame (main.ts:528-548)
+    rng = np.random.default_rng(5)
+    sdf = rng.integers(0, 900, size=2160 * 64).astype(np.uint16)
+    parts = [sdf[r::8] for r in range(8)]
+    assert sum(int(p.sum()) for p in parts) == int(sdf.sum())
+    assert max(int(p.max()) for p in parts) == int(sdf.max()) and min(int(p.min()) for p in parts) == int(sdf.min())

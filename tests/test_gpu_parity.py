@@ -87,9 +87,11 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, item_px=64), dict(kernel=2, item_px=256, tile_w=32), dict(kernel=2, item_px=128, tile_w=64),
                      dict(kernel=2, static=75), dict(kernel=2, static=95, item_px=64),
                      dict(kernel=2, nn=1, coop=0), dict(kernel=2, uniform=0), dict(kernel=2, uniform=0, list_cap=2),
-                     dict(kernel=2, rel=0), dict(kernel=2, rel=0, uniform=0), dict(kernel=2, rel=1, list_cap=2)]:
+                     dict(kernel=2, rel=0), dict(kernel=2, rel=0, uniform=0), dict(kernel=2, rel=1, list_cap=2),
+                     dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16),
+                     dict(kernel=2, lds_kb=64, rel=0)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)

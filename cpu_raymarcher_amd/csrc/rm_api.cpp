@@ -38,6 +38,8 @@ struct DeviceScene {
     int32_t *oct_lut = nullptr;
     uint32_t *oct_sub_hdr = nullptr;
     uint8_t *oct_sub_list = nullptr;
+    uint16_t *bvh_leaves = nullptr;  // node indices of the non-empty BVH leaves, increasing (v2 bundle cull)
+    int32_t bvh_leaf_count = 0;      // 0: no cull (no BVH, too many leaves, or a leaf box not inside its ancestors')
 };
 
 }  // namespace
@@ -85,6 +87,7 @@ struct rm_ctx {
     int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
                              // frames overlap (bench.py sets 75 with frames in flight); alone it costs the frame its balance
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
+    int64_t opt_cull = 1;     // v2: whole 64-pixel batches find their hit leaves by a bundle-frustum cull instead of the tree walk
     int64_t opt_rel = 1;      // v2: BVH node boxes relative to the frame's ray origin, as doubles in LDS (slab test without conversions)
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
@@ -134,6 +137,7 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.oct_lut);
     (void)hipFree(d.oct_sub_hdr);
     (void)hipFree(d.oct_sub_list);
+    (void)hipFree(d.bvh_leaves);
     d = DeviceScene();
 }
 
@@ -169,6 +173,34 @@ int upload_scene(rm_ctx *ctx) {
     if ((rc = upload_vec(ctx, ctx->host.oct_lut, &ctx->dev.oct_lut))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_sub_hdr, &ctx->dev.oct_sub_hdr))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.oct_sub_list, &ctx->dev.oct_sub_list))) return rc;
+    // Leaf table of the bundle cull (rm_render_v2.hip, bvh_prologue_cull).  The cull tests leaves directly, which
+    // equals the reference's traversal only if a hit leaf implies hit ancestors: every box must lie inside its
+    // parent's, bit for bit (the builder takes unions, so it does; verified here rather than assumed).
+    {
+        const auto &bvh = ctx->host.bvh;
+        std::vector<uint16_t> leaves;
+        bool ok = !bvh.empty() && bvh.size() < 65536;
+        std::vector<int> parent(bvh.size(), -1);
+        for (size_t i = 0; ok && i < bvh.size(); ++i) {
+            if (bvh[i].leaf >= 0) continue;
+            for (size_t c = i + 1; c < static_cast<size_t>(bvh[i].skip) && c < bvh.size(); c = static_cast<size_t>(bvh[c].skip)) {
+                parent[c] = static_cast<int>(i);
+                if (bvh[c].skip <= static_cast<int>(c)) { ok = false; break; }
+            }
+        }
+        for (size_t i = 0; ok && i < bvh.size(); ++i) {
+            if (parent[i] >= 0)
+                for (int k = 0; k < 3; ++k)
+                    if (!(bvh[i].lo[k] >= bvh[parent[i]].lo[k] && bvh[i].hi[k] <= bvh[parent[i]].hi[k])) ok = false;
+            for (int k = 0; k < 3; ++k)  // a negative radius gives lo > hi: the slab test then is not monotone in the box
+                if (!(bvh[i].lo[k] <= bvh[i].hi[k])) ok = false;
+            if (i > 0 && parent[i] < 0) ok = false;  // not reached through the skip links: unknown shape
+            if (bvh[i].leaf >= 0 && (bvh[i].leaf & 0xFF) > 0) leaves.push_back(static_cast<uint16_t>(i));
+        }
+        if (!ok || leaves.size() > 256) leaves.clear();
+        ctx->dev.bvh_leaf_count = static_cast<int32_t>(leaves.size());
+        if ((rc = upload_vec(ctx, leaves, &ctx->dev.bvh_leaves))) return rc;
+    }
     return RM_OK;
 }
 
@@ -357,6 +389,8 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.use_grid = (ctx->opt_grid && !ctx->host.pq_cells.empty()) ? 1 : 0;
     p.pq_cells = ctx->dev.pq_cells;
     p.pq_list = ctx->dev.pq_list;
+    p.bvh_leaves = ctx->dev.bvh_leaves;
+    p.bvh_leaf_count = (ctx->opt_cull && ctx->host.accel == RM_ACCEL_BVH) ? ctx->dev.bvh_leaf_count : 0;
     p.nn_cells = ctx->dev.nn_cells;
     p.nn_list = ctx->dev.nn_list;
     p.nn_cell_count = static_cast<int32_t>(ctx->host.nn_cells.size());
@@ -928,6 +962,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lds_kb = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "cull")) {
+        ctx->opt_cull = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "rel")) {
         ctx->opt_rel = value ? 1 : 0;
         return RM_OK;
@@ -989,6 +1027,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "static")) *value = ctx->opt_static;
     else if (!std::strcmp(key, "uniform")) *value = ctx->opt_uniform;
     else if (!std::strcmp(key, "rel")) *value = ctx->opt_rel;
+    else if (!std::strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;

@@ -556,6 +556,106 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
     return have;
 }
 
+// The same result for a whole 64-pixel batch without the tree walk.  A leaf's box lies inside every ancestor's (checked
+// by the host), and every operation of the slab test is monotone, so a ray hits a leaf exactly when the leaf's own
+// test passes: the set of recorded leaves is {non-empty leaves whose test passes}, in increasing node index.  The
+// batch's rays form a bundle through the pixel rectangle [u0, u1] x [v0, v1]: a point s (u c0 + v c1 - c2), s >= 0, of
+// such a ray satisfies q.(c0 + u0 c2) >= 0, q.(c0 + u1 c2) <= 0 and the same with c1 and v, so a box that lies
+// entirely on the wrong side of one of those four planes through the origin is hit by no ray of the bundle.  Each lane
+// culls one leaf (binary32, the rectangle widened by half a pixel spacing -- a hundred times the rounding error of
+// the dot products and of the ray directions), a ballot collects the survivors, and all lanes run the exact test on
+// those only.  Rays outside the frame (`active` false) take part in the cull but record nothing.
+struct Bundle {
+    float n[4][3];  // plane normals: left, right, bottom, top (keep side: >= 0, <= 0, >= 0, <= 0)
+};
+__device__ __forceinline__ Bundle make_bundle(const RmRenderParams &C, int x0, int x1, int y0, int y1) {
+    const float mu = __builtin_fmaxf(1.0f / static_cast<float>(C.width), 1e-4f);
+    const float mv = __builtin_fmaxf(1.0f / static_cast<float>(C.height), 1e-4f);
+    const float u0 = (static_cast<float>(x0) / static_cast<float>(C.width) - 0.5f) * 2.0f - mu;
+    const float u1 = (static_cast<float>(x1) / static_cast<float>(C.width) - 0.5f) * 2.0f + mu;
+    const float v0 = (static_cast<float>(y0) / static_cast<float>(C.height) - 0.5f) * 2.0f - mv;
+    const float v1 = (static_cast<float>(y1) / static_cast<float>(C.height) - 0.5f) * 2.0f + mv;
+    Bundle b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // make_ray: d = u c0 + v c1 - c2 with c0 = rot[0..2], c1 = rot[3..5], c2 = rot[6..8]
+        b.n[0][k] = C.rot[k] + u0 * C.rot[6 + k];
+        b.n[1][k] = C.rot[k] + u1 * C.rot[6 + k];
+        b.n[2][k] = C.rot[3 + k] + v0 * C.rot[6 + k];
+        b.n[3][k] = C.rot[3 + k] + v1 * C.rot[6 + k];
+    }
+    return b;
+}
+__device__ __forceinline__ bool bundle_misses_box(const Bundle &b, const float lo[3], const float hi[3], const float o[3]) {
+    const float ql[3] = {lo[0] - o[0], lo[1] - o[1], lo[2] - o[2]};
+    const float qh[3] = {hi[0] - o[0], hi[1] - o[1], hi[2] - o[2]};
+    bool miss = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float mx = 0.f, mn = 0.f;  // max / min over the box's corners of q . n
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = ql[k] * b.n[p][k], c = qh[k] * b.n[p][k];
+            mx += __builtin_fmaxf(a, c);
+            mn += __builtin_fminf(a, c);
+        }
+        miss = miss || ((p & 1) ? mn > 0.f : mx < 0.f);
+    }
+    return miss;
+}
+
+template <bool REL>
+__device__ bool bvh_prologue_cull(const SceneView &S, const RmRenderParams &C, const Bundle &B, bool active, const Ray &r,
+                                  const RayInv &ri, RayList &L, Interval &first, int lane) {
+    bool have = false;
+    L.cnt = 0;
+    {   // the root first: a batch of background rays ends here, as it does in the tree walk
+        const RmBvhNode root = S.nodes[0];
+        double tE = 0.0, tX = 0.0;
+        const bool hit = active && node_slab<REL>(S, root, 0, r, ri, tE, tX) && !(tX < 0.0) && !(tE > RM_MAX_DIST);
+        if (!__any(hit)) {
+            L.live = 0;
+            return false;
+        }
+        active = hit;  // a ray that misses the root hits no leaf
+    }
+    const float o[3] = {C.origin[0], C.origin[1], C.origin[2]};
+    for (int j0 = 0; j0 < C.bvh_leaf_count; j0 += 64) {  // wave-uniform trip count
+        const int j = j0 + lane;
+        int li = 0;
+        bool cand = false;
+        if (j < C.bvh_leaf_count) {
+            li = C.bvh_leaves[j];
+            const RmBvhNode nd = S.nodes[li];
+            cand = !bundle_misses_box(B, nd.lo, nd.hi, o);
+        }
+        unsigned long long m = __ballot(cand);
+        while (m) {  // survivors in increasing node index = traversal order
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int i = __builtin_amdgcn_readlane(li, src);
+            RM_CNT(5)
+            if (active) {
+                const RmBvhNode node = S.nodes[i];
+                double tE, tX;
+                if (node_slab<REL>(S, node, i, r, ri, tE, tX) && !(tX < 0.0) && !(tE > RM_MAX_DIST)) {  // bvh.ts:145,151,165
+                    const double cE = __builtin_fmax(tE, 0.0);
+                    const double cX = __builtin_fmin(tX, RM_MAX_DIST);
+                    if (L.cnt < L.cap) L.col[L.cnt * 64] = static_cast<uint16_t>(i);
+                    L.cnt++;
+                    if (!have || cE < first.tEnter) {
+                        first.tEnter = cE;
+                        first.tExit = cX;
+                        first.ord = i;
+                        have = true;
+                    }
+                }
+            }
+        }
+    }
+    L.live = L.cnt;
+    return have;
+}
+
 // successor of key (keyT, keyOrd) in the stable-sorted interval order of bvh.ts:176
 template <bool REL>
 __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, RayList &L, double keyT, int keyOrd,
@@ -837,12 +937,17 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                 const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(idle >> 32),
                                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(idle), 0u));
                 const bool take = phase == PH_DONE && rank < remaining;
+                bool in_frame = false;  // this lane received a pixel inside the frame
+                // a whole batch from one 64-pixel sub-tile (the normal case): its hit leaves come from the bundle cull
+                const bool whole_batch = ACCEL == 2 && C.bvh_leaf_count > 0 && n_idle == 64 && (qpos & 63) == 0;
+                const int batch_sub = qpos >> 6;
                 if (take) {
                     const int n = qpos + rank;  // pixel n of the tile, in 64-pixel sub-tile order
                     const int sub = n >> 6, l = n & 63;
                     px = (tile_col << C.tile_w_log2) + (l & (Q.tile_w - 1));
                     prow = (tile_row << C.tile_h_log2) + sub * (64 >> C.tile_w_log2) + (l >> C.tile_w_log2);
                     if (px < C.width && prow < C.local_rows) {
+                        in_frame = true;
                         have_pixel = true;
                         ray = make_ray(C, px, row_to_y(C, prow));
                         count = 0;
@@ -851,22 +956,31 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                         t = 0.0;
                         nx = ny = nz = 0.f;
                         phase = PH_MARCH;
-                        if (ACCEL == 2) {
-                            RM_CNT(15)
-                            ri = make_ray_inv(ray);
+                        if (ACCEL == 2) ri = make_ray_inv(ray);
+                    }
+                }
+                if (ACCEL == 2) {
 #ifdef RM_STAMPS
-                            const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
+                    const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
 #endif
-                            haveCur = bvh_prologue<REL>(S, ray, ri, L, cur);
+                    if (whole_batch) {
+                        const int x0 = tile_col << C.tile_w_log2;
+                        const int r0 = (tile_row << C.tile_h_log2) + batch_sub * (64 >> C.tile_w_log2);
+                        const Bundle B = make_bundle(C, x0, x0 + Q.tile_w - 1, row_to_y(C, r0),
+                                                     row_to_y(C, r0 + (64 >> C.tile_w_log2) - 1));
+                        const bool hc = bvh_prologue_cull<REL>(S, C, B, in_frame, ray, ri, L, cur, lane);
+                        if (in_frame) haveCur = hc;
+                    } else if (in_frame) {
+                        RM_CNT(15)
+                        haveCur = bvh_prologue<REL>(S, ray, ri, L, cur);
+                    }
 #ifdef RM_STAMPS
-                            t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
-                            t_prev_ += __builtin_amdgcn_s_memtime() - t_pr0;
+                    t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
+                    t_prev_ += __builtin_amdgcn_s_memtime() - t_pr0;
 #endif
-                            if (!haveCur) {  // bvh.ts:190-192: exactly MAX_DIST, zero normal
-                                t = RM_MAX_DIST;
-                                phase = PH_DONE;
-                            }
-                        }
+                    if (in_frame && !haveCur) {  // bvh.ts:190-192: exactly MAX_DIST, zero normal
+                        t = RM_MAX_DIST;
+                        phase = PH_DONE;
                     }
                 }
                 qpos += n_idle < remaining ? n_idle : remaining;

@@ -132,6 +132,8 @@ struct RmRenderParams {
     unsigned long long *stamps;   // diagnostic build (-DRM_STAMPS) only: 8 cycle accumulators
     const uint32_t *pq_cells;
     const uint16_t *pq_list;
+    const uint16_t *bvh_leaves;  // v2 bundle cull: node indices of the non-empty leaves, increasing; bvh_leaf_count entries (0: off)
+    int32_t bvh_leaf_count, reserved4;
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;

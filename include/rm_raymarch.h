@@ -298,6 +298,7 @@ RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
  *   static 0..95 percent of every tile queue assigned to the waves without atomics (v2; for overlapping frames)
  *   uniform 0|1   scenes whose spheres share one radius: rank leaf candidates by squared centre distance (v2, default 1)
  *   rel 0|1       BVH node boxes relative to the frame's ray origin, as doubles in LDS, when they fit (v2, default 1)
+ *   cull 0|1      whole 64-pixel batches find their hit BVH leaves by a bundle-frustum cull (v2, <= 256 leaves, default 1)
  *   lds_kb 16..64 LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (32: five workgroups per CU; 40: four) */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);

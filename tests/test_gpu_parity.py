@@ -89,9 +89,9 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, nn=1, coop=0), dict(kernel=2, uniform=0), dict(kernel=2, uniform=0, list_cap=2),
                      dict(kernel=2, rel=0), dict(kernel=2, rel=0, uniform=0), dict(kernel=2, rel=1, list_cap=2),
                      dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16),
-                     dict(kernel=2, lds_kb=64, rel=0)]:
+                     dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32, cull=1).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -127,6 +127,38 @@ def test_one_radius_scenes_rank_by_squared_distance(rm, oracle):
             for o in outs[1:]:
                 assert_same(o, outs[0], "uniform radius variants %s" % accel)
             assert_same(outs[0], cpu_render(oracle, None, accel, 200, 120, (0.2, 0.5), spheres=sp), "vs oracle")
+
+
+def test_bundle_cull_matches_tree_walk(rm, oracle):
+    """Whole 64-pixel batches find their hit BVH leaves by a bundle-frustum cull (option `cull`) instead of the tree
+    walk: same bytes as the walk and as the oracle for frames with partial tiles, row sub-ranges, several tile shapes,
+    cameras from every side, and boxes that contain the camera."""
+    import numpy as np
+    ctx = rm.Context(0)
+    rng = np.random.default_rng(404)
+    scenes = []
+    c = rng.uniform(-2.5, 2.5, size=(150, 3))
+    scenes.append(np.concatenate([c, rng.uniform(0.05, 0.5, size=(150, 1))], axis=1))
+    big = np.concatenate([rng.uniform(-1.5, 1.5, size=(40, 3)), rng.uniform(0.1, 0.4, size=(40, 1))], axis=1)
+    big[0] = (0.0, 0.0, 0.0, 7.0)   # encloses the camera and every other sphere
+    big[1] = (0.0, 0.0, 4.5, 1.5)   # around the default camera position
+    scenes.append(big)
+    scenes.append(np.concatenate([rng.uniform(-0.2, 0.2, size=(30, 3)) * (1, 30, 1), np.full((30, 1), 0.15)], axis=1))  # a tall thin column
+    for sp in scenes:
+        sp = sp.astype(np.float32).astype(np.float64)
+        for (W, H, rows, ang) in [(77, 53, None, (0.0, 0.0)), (130, 70, (13, 59), (0.4, 2.2)), (96, 64, None, (-1.2, 4.0)),
+                                  (64, 48, None, (1.5, 0.3))]:
+            outs = []
+            for opts in (dict(cull=1), dict(cull=0), dict(cull=1, tile_w=8, item_px=256), dict(cull=1, tile_w=32, item_px=64),
+                         dict(cull=1, rel=0, uniform=0), dict(cull=1, refill=24), dict(cull=1, list_cap=2), dict(kernel=1)):
+                for k, v in dict(kernel=2, cull=1, tile_w=16, item_px=128, rel=1, uniform=1, refill=64, list_cap=32).items():
+                    ctx.set_option(k, v)
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                outs.append(gpu_render(rm, ctx, None, "BVH", W, H, ang, rows=rows, spheres=sp))
+            for o in outs[1:]:
+                assert_same(o, outs[0], "bundle cull variants %dx%d" % (W, H))
+            assert_same(outs[0], cpu_render(oracle, None, "BVH", W, H, ang, rows=rows, spheres=sp), "vs oracle")
 
 
 def test_frames_in_flight_on_separate_streams(rm):

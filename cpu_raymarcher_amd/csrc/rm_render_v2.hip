@@ -591,14 +591,20 @@ __device__ __forceinline__ bool bundle_misses_box(const Bundle &b, const float l
     bool miss = false;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        float mx = 0.f, mn = 0.f;  // max / min over the box's corners of q . n
+        float mx = 0.f, mn = 0.f, mag = 0.f;  // max / min over the box's corners of q . n; sum of the term magnitudes
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float a = ql[k] * b.n[p][k], c = qh[k] * b.n[p][k];
             mx += __builtin_fmaxf(a, c);
             mn += __builtin_fminf(a, c);
+            mag += __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(c));
         }
-        miss = miss || ((p & 1) ? mn > 0.f : mx < 0.f);
+        // the binary32 sums are within 1e-6 * mag of the real ones (roundings of q, n, the products and the two
+        // additions: < 6e-7 * mag): a box is only dropped when it is outside by more than that, whatever its size
+        // (the half-pixel widening alone shrinks with the distance to the camera; a large box that passes close to
+        // the camera, almost in a side plane, needs the absolute term)
+        const float tol = 1e-6f * mag;
+        miss = miss || ((p & 1) ? mn > tol : mx < -tol);
     }
     return miss;
 }

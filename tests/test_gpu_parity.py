@@ -144,6 +144,13 @@ def test_bundle_cull_matches_tree_walk(rm, oracle):
     big[1] = (0.0, 0.0, 4.5, 1.5)   # around the default camera position
     scenes.append(big)
     scenes.append(np.concatenate([rng.uniform(-0.2, 0.2, size=(30, 3)) * (1, 30, 1), np.full((30, 1), 0.15)], axis=1))  # a tall thin column
+    # small spheres strung along the left, right and bottom edges of the default camera's view pyramid, starting 3 cm
+    # from the camera (orbit radius 3, camera.ts:13): boxes that graze the cull's planes next to the apex
+    s_ = np.concatenate([np.linspace(0.03, 0.3, 12), np.linspace(0.4, 4.0, 12)])
+    edge = [np.stack([-s_, 0 * s_, 3.0 - s_], axis=1), np.stack([s_, 0.3 * s_, 3.0 - s_], axis=1),
+            np.stack([0.2 * s_, -s_, 3.0 - s_], axis=1)]
+    edge = np.concatenate(edge)
+    scenes.append(np.concatenate([edge, np.full((len(edge), 1), 0.02)], axis=1))
     for sp in scenes:
         sp = sp.astype(np.float32).astype(np.float64)
         for (W, H, rows, ang) in [(77, 53, None, (0.0, 0.0)), (130, 70, (13, 59), (0.4, 2.2)), (96, 64, None, (-1.2, 4.0)),

@@ -562,9 +562,9 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
 // batch's rays form a bundle through the pixel rectangle [u0, u1] x [v0, v1]: a point s (u c0 + v c1 - c2), s >= 0, of
 // such a ray satisfies q.(c0 + u0 c2) >= 0, q.(c0 + u1 c2) <= 0 and the same with c1 and v, so a box that lies
 // entirely on the wrong side of one of those four planes through the origin is hit by no ray of the bundle.  Each lane
-// culls one leaf (binary32, the rectangle widened by half a pixel spacing -- a hundred times the rounding error of
-// the dot products and of the ray directions), a ballot collects the survivors, and all lanes run the exact test on
-// those only.  Rays outside the frame (`active` false) take part in the cull but record nothing.
+// culls one leaf (binary32; the rectangle widened by half a pixel spacing -- a hundred times the rounding error of
+// the ray directions -- and a tolerance for the dot products' own roundings, bundle_misses_box), a ballot collects
+// the survivors, and all lanes run the exact test on those only.  Rays outside the frame (`active` false) take part in the cull but record nothing.
 struct Bundle {
     float n[4][3];  // plane normals: left, right, bottom, top (keep side: >= 0, <= 0, >= 0, <= 0)
 };

@@ -461,7 +461,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/traffic.json"
                          if traffic else None,
-                         "kernel": "render_kernel_v2<2,true,true,true>" if args.workload == "C3" else "render kernel",
+                         "kernel": "render_kernel_v2<2, true, true, false>" if args.workload == "C3" else "render kernel",
                          "kernel_ms": kern_serial_ms, "kernel_ms_in_flight": kern_ms, "frames_in_flight": S,
                          "persistent_workgroups_per_cu": in_flight_bpc or 4,
                          "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rm_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rm_selftest_hypot": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "rm_selftest_fastdiv": (C.c_int, [_VP, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]),
+    "rm_selftest_recip": (C.c_int, [_VP, C.c_int, _VP]),
     "rm_debug_read_stamps": (C.c_int, [_VP, _VP]),
     "rm_debug_read_counts": (C.c_int, [_VP, _VP]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),

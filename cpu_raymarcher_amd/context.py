@@ -201,6 +201,17 @@ def _selftest_fastdiv(self, seed, n):
 Context.selftest_fastdiv = _selftest_fastdiv
 
 
+def _selftest_recip(self, mode):
+    """Exhaustive device-side check of the range-restricted division of ray set-up (mode 0: 1.0 / d for every finite
+    non-zero binary32 d; mode 1: x / W for 0 <= x < 65536, 1 <= W < 65536); returns the mismatch count."""
+    out = C.c_uint64(0)
+    N.check(self._h, N.lib().rm_selftest_recip(self._h, int(mode), C.byref(out)))
+    return out.value
+
+
+Context.selftest_recip = _selftest_recip
+
+
 def make_transform(x, y, z, rotation=None):
     """SceneManager.getTransform (sceneManager.ts:21-37) -> world->local float32[16]."""
     out = np.zeros(16, np.float32)

@@ -896,6 +896,23 @@ int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *mismatc
     return RM_OK;
 }
 
+int rm_selftest_recip(rm_ctx *ctx, int mode, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (mode != 0 && mode != 1) return fail(ctx, RM_E_INVALID, "mode must be 0 or 1");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, 256);
+    if (rc) return rc;
+    unsigned long long *d = static_cast<unsigned long long *>(ctx->scratch);
+    RM_HIP(ctx, hipMemsetAsync(d, 0, sizeof *d, ctx->stream));
+    RM_HIP(ctx, rm_launch_recip_selftest(mode, d, ctx->stream));
+    unsigned long long h = 0;
+    RM_HIP(ctx, hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = h;
+    return RM_OK;
+}
+
 int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8) {
     if (!ctx || !out8) return RM_E_INVALID;
     if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");

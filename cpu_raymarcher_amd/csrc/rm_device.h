@@ -94,6 +94,21 @@ __device__ __forceinline__ double hypot3_shared_rcp(float lx, float ly, float lz
     return sqrt_unit_range(sum) * big;  // the largest scaled square is exactly 1: sum in [1, 3]
 }
 
+// a / b as the compiler's IEEE expansion computes it when v_div_scale has nothing to scale (reciprocal estimate, two
+// Newton steps, quotient, one correction) without the scale / fmas / fixup bracket: 8 instead of ~30 instructions.
+// Used only where the operand ranges are known and the equality was checked EXHAUSTIVELY on the device
+// (rm_selftest_recip): 1.0 / d for every finite non-zero binary32 d, and x / W for all integers 0 <= x < 2^16,
+// 1 <= W < 2^16.
+__device__ __forceinline__ double div_in_range(double a, double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-b, r1, 1.0);
+    const double r2 = __builtin_fma(r1, e1, r1);
+    const double q = a * r2;
+    return __builtin_fma(__builtin_fma(-b, q, a), r2, q);
+}
+
 struct Vec3f {
     float x, y, z;
 };
@@ -309,7 +324,7 @@ __device__ __forceinline__ RayInv make_ray_inv(const Ray &r) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         ri.par[a] = __builtin_fabs(static_cast<double>(d[a])) < 1e-10;
-        ri.inv[a] = ri.par[a] ? 0.0 : 1.0 / static_cast<double>(d[a]);
+        ri.inv[a] = ri.par[a] ? 0.0 : div_in_range(1.0, static_cast<double>(d[a]));  // d finite, |d| >= 1e-10
     }
     ri.any_par = ri.par[0] || ri.par[1] || ri.par[2];
     return ri;
@@ -459,8 +474,16 @@ __device__ __forceinline__ int row_to_y(const RmRenderParams &P, int r) {
 
 // raymarcher.ts:73,83-88: u, v from full-frame W, H; fromValues, transformMat3, normalize
 __device__ __forceinline__ Ray make_ray(const RmRenderParams &P, int x, int y) {
-    const double v = (static_cast<double>(y) / static_cast<double>(P.height) - 0.5) * 2.0;
-    const double u = (static_cast<double>(x) / static_cast<double>(P.width) - 0.5) * 2.0;
+    double qy, qx;
+    if (P.width < 65536 && P.height < 65536) {  // wave-uniform: the quotients are in the exhaustively checked range
+        qy = div_in_range(static_cast<double>(y), static_cast<double>(P.height));
+        qx = div_in_range(static_cast<double>(x), static_cast<double>(P.width));
+    } else {
+        qy = static_cast<double>(y) / static_cast<double>(P.height);
+        qx = static_cast<double>(x) / static_cast<double>(P.width);
+    }
+    const double v = (qy - 0.5) * 2.0;
+    const double u = (qx - 0.5) * 2.0;
     const double ax = to_f32(u), ay = to_f32(v), az = -1.0;
     const float dx = to_f32(ax * P.rot_d[0] + ay * P.rot_d[3] + az * P.rot_d[6]);
     const float dy = to_f32(ax * P.rot_d[1] + ay * P.rot_d[4] + az * P.rot_d[7]);

@@ -41,3 +41,4 @@ hipError_t rm_launch_jsmath(int fn, const double *a, const double *b, int64_t n,
 
 // compares the two device forms of Math.hypot on n generated triples; adds mismatches
 hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t rm_launch_recip_selftest(int mode, unsigned long long *d_mismatches, hipStream_t stream);

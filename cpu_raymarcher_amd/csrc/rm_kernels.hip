@@ -674,7 +674,38 @@ __global__ __launch_bounds__(256) void fastdiv_selftest_kernel(uint64_t seed, in
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+// mode 0: 1.0 / d for every finite non-zero binary32 d (2^32 bit patterns); mode 1: x / W for 0 <= x < 2^16, 1 <= W < 2^16
+__global__ __launch_bounds__(256) void recip_selftest_kernel(int mode, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < (1ull << 32);
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        double a, b;
+        if (mode == 0) {
+            const float d = __uint_as_float(static_cast<uint32_t>(i));
+            if (!(__builtin_fabsf(d) <= 3.4028234663852886e38f) || d == 0.0f) continue;
+            a = 1.0;
+            b = static_cast<double>(d);
+        } else {
+            const uint32_t x = static_cast<uint32_t>(i >> 16), w = static_cast<uint32_t>(i & 0xFFFFu);
+            if (w == 0) continue;
+            a = static_cast<double>(x);
+            b = static_cast<double>(w);
+        }
+        // opaque to the optimiser, so that the reference quotient is the compiler's full IEEE expansion
+        asm volatile("" : "+v"(a), "+v"(b));
+        const double want = a / b, got = div_in_range(a, b);
+        if (__double_as_longlong(want) != __double_as_longlong(got)) bad++;
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
+
+hipError_t rm_launch_recip_selftest(int mode, unsigned long long *d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(recip_selftest_kernel, dim3(4096), dim3(256), 0, stream, mode, d_mismatches);
+    return hipGetLastError();
+}
 
 hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long long *d_mismatches, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

@@ -279,6 +279,11 @@ RM_API int rm_selftest_jsmath(rm_ctx *ctx, int32_t fn, const double *a, const do
  * binary32 triples (zeros, denormals, equal magnitudes included) and counts bitwise mismatches. */
 RM_API int rm_selftest_fastdiv(rm_ctx *ctx, uint64_t seed, int64_t n, uint64_t *mismatches);
 
+/* Device self-test of the range-restricted division of ray set-up (rm_device.h div_in_range) against the compiler's IEEE
+ * division, EXHAUSTIVE over its domain: mode 0 = 1.0 / d for every finite non-zero binary32 d; mode 1 = x / W for all
+ * integers 0 <= x < 65536, 1 <= W < 65536.  Counts bitwise mismatches (2^32 cases per mode, about a second). */
+RM_API int rm_selftest_recip(rm_ctx *ctx, int mode, uint64_t *mismatches);
+
 /* Diagnostic builds only (make EXTRA=-DRM_STAMPS): reads and clears eight per-section cycle
  * accumulators of the v2 wave loop (all zero in the product build). */
 RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);

@@ -70,6 +70,14 @@ def test_shared_reciprocal_division_is_bit_identical(gpu_ctx):
     assert gpu_ctx.selftest_fastdiv(0xBEEF, 50_000_000) == 0
 
 
+def test_ray_setup_division_is_the_ieee_division(gpu_ctx):
+    """Ray set-up divides without the scale / fix-up bracket of the compiler's IEEE expansion where the operand ranges
+    make it a no-op.  Exhaustive: every finite non-zero binary32 denominator of 1.0 / d, and every x / W with
+    0 <= x < 65536, 1 <= W < 65536 (2^32 cases each)."""
+    assert gpu_ctx.selftest_recip(0) == 0
+    assert gpu_ctx.selftest_recip(1) == 0
+
+
 def test_v1_and_v2_kernels_agree(rm, oracle):
     """Two independently structured kernels (divergent per-ray loops with native divisions vs
     the uniform wave loop with lists / cooperative fallback / shared reciprocal) must produce

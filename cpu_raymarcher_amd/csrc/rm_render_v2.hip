@@ -508,7 +508,8 @@ struct RayList {
     uint16_t *col;  // this lane's column: entry e at col[e * 64]
     int cap;
     int cnt;        // leaves hit (may exceed cap -> overflow)
-    int live;       // entries still listed: bvh_next drops the ones that can no longer be a successor
+    int live;       // entries still listed: the current interval's entry and the ones after it
+    int cur_pos;    // list position of the current interval's entry (bvh_next removes it first)
 };
 
 // BVH.onRayMarchStart (bvh.ts:181-202): one traversal; records hit leaves, returns the first
@@ -548,6 +549,7 @@ __device__ bool bvh_prologue(const SceneView &S, const Ray &r, const RayInv &ri,
                 first.tExit = cX;
                 first.ord = i;
                 have = true;
+                L.cur_pos = L.cnt - 1;
             }
         }
         i = node.skip;
@@ -653,6 +655,7 @@ __device__ bool bvh_prologue_cull(const SceneView &S, const RmRenderParams &C, c
                         first.tExit = cX;
                         first.ord = i;
                         have = true;
+                        L.cur_pos = L.cnt - 1;
                     }
                 }
             }
@@ -669,12 +672,16 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, Ray
     bool have = false;
     RM_CNT(3)
     if (L.cnt <= L.cap) {
-        // Keys only grow over a ray's life, so an entry that is not after this key is not after any later one: it
-        // is dropped (the last live entry takes its place), and the list a ray scans shrinks as the ray advances.
-        // The list is then no longer in traversal order, so ties between equal tEnter go to the smaller node index
-        // explicitly (traversal order = increasing index: the stackless walk only moves forward).
-        int e = 0;
-        while (e < L.live) {
+        // The list holds the current interval's entry and the entries AFTER it in the order of bvh.ts:176 -- nothing
+        // else: the first interval is the minimum of all of them, every later one the minimum of what remained.  So the
+        // successor is the minimum of the list without the current entry; that entry is removed by position (the last
+        // entry takes its place) before the scan, no entry needs the `after` test, and the list a ray scans shrinks by
+        // one per advance: c (c - 1) / 2 slab tests over a ray's life instead of c^2.  The list is not in traversal order
+        // any more, so ties between equal tEnter go to the smaller node index explicitly (traversal order = increasing
+        // index: the stackless walk only moves forward).
+        L.live -= 1;
+        if (L.cur_pos != L.live) L.col[L.cur_pos * 64] = L.col[L.live * 64];
+        for (int e = 0; e < L.live; ++e) {
             RM_CNT(4)
             const int id = L.col[e * 64];
             const RmBvhNode node = S.nodes[id];
@@ -682,19 +689,13 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, Ray
             node_slab<REL>(S, node, id, r, ri, tE, tX);  // hit by construction; same arithmetic, same values
             const double cE = __builtin_fmax(tE, 0.0);
             const double cX = __builtin_fmin(tX, RM_MAX_DIST);
-            const bool after = cE > keyT || (cE == keyT && id > keyOrd);
-            if (!after) {
-                L.live -= 1;
-                L.col[e * 64] = L.col[L.live * 64];
-                continue;
-            }
             if (!have || cE < out.tEnter || (cE == out.tEnter && id < out.ord)) {
                 out.tEnter = cE;
                 out.tExit = cX;
                 out.ord = id;
                 have = true;
+                L.cur_pos = e;
             }
-            e += 1;
         }
         return have;
     }
@@ -852,6 +853,7 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
     L.cap = P.list_cap;
     L.cnt = 0;
     L.live = 0;
+    L.cur_pos = 0;
     L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
     const bool coop = P.coop != 0, filter = P.filter != 0;
 

@@ -149,6 +149,12 @@ def main():
                          "frame's persistent kernel (its slowest rays) overlaps the next frames; 1 = strictly serial")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON record: libraries that write to file descriptor 1 themselves (RCCL prints
+    # a five-line version banner there when a process group starts) are sent to stderr until that line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import cpu_raymarcher_amd as R
@@ -496,6 +502,8 @@ def main():
             js = js_engine_baseline(wl)
             if js:
                 out["cpu_baseline"]["js_engine_single_thread"] = js
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -16,7 +16,7 @@ and combines the partial sums -- total work fixed, so scaling is "strong".
 Frames are independent, so `--frames-in-flight S` (default 12) enqueues consecutive frames on S HIP streams with
 S buffer sets: the tail of a frame's persistent kernel -- its slowest rays, ~0.3 ms during which most CUs idle --
 overlaps the following frames.  Every frame is still rendered, shaded and reduced in full; S = 1 is strictly serial.
-With frames in flight a launch uses two persistent workgroups per CU instead of four (the other frames' workgroups
+With frames in flight a launch uses one persistent workgroup per CU instead of four (the other frames' workgroups
 fill the CU) and the process asks the HIP runtime for sixteen hardware queues (GPU_MAX_HW_QUEUES, default four) so
 that the streams do not share queues.
 
@@ -206,15 +206,15 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    # With frames in flight a launch runs best with half as many persistent workgroups (two per CU): the other
-    # frames' workgroups fill the CUs, and each workgroup stages the scene tables once for twice as many tiles.
-    # Whole frame 617 -> 621 frames/s at six streams, 640 at eight streams on eight hardware queues; the 1/8-row
-    # shard of an 8-GPU job 0.46 -> 0.29 ms per frame (scripts/overlap_probe.py, scripts/bench_variants.sh).  The
-    # static tile share (option `static`) lost to this setting and is no longer used here.
+    # With frames in flight a launch runs best with few persistent workgroups (one per CU): the other frames' workgroups
+    # fill the CUs, and each workgroup stages the scene tables once for four times as many tiles.  Measured on the final
+    # kernel (scripts/bench_variants.sh, scripts/overlap_probe.py): whole frame 858 (one per CU), 841 (two), 825 (three)
+    # frames/s; the 1/8-row shard of an 8-GPU job 0.22 (one) against 0.26 ms (two) per frame.  The static tile share
+    # (option `static`) lost to this setting and is no longer used here.
     in_flight_bpc = None
     in_flight_opts = {}  # option -> (value with frames in flight, library default restored for the launch measured alone)
     if max(1, args.frames_in_flight) > 1:
-        in_flight_opts["blocks_per_cu"] = (2, 4)
+        in_flight_opts["blocks_per_cu"] = (1, 4)  # final kernel: one per CU 858, two 841 frames/s; 1/8-row shard 0.22 against 0.26 ms
         if world == 1:  # whole frames: 256-pixel work items of 8 x 32 pixels (744 -> 763 frames/s; alone 2.00 -> 2.24 ms)
             in_flight_opts["item_px"] = (256, 128)
             in_flight_opts["tile_w"] = (8, 16)

@@ -9,34 +9,49 @@ A step = one frame of BASELINE.json's metric workload (C3: Dense Sphere Grid, 12
 3840x2160, sphere tracing + BVH, iteration-heatmap shader): render + fused shade into
 {depth, normal, sdfEval, iters, RGBA} resident in HBM, then the diagnostics reduction of
 main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the ranks
-(interleaved 16-row stripes); every rank reduces the counters of its own rows, and one gather
-brings its RGBA rows and its 32-byte partial diagnostics to rank 0, which reassembles the frame
-and combines the partial sums -- total work fixed, so scaling is "strong".
+(interleaved 16-row stripes, dealt by a weighted round-robin: rank 0 also reassembles the frame, so it renders a
+smaller share); every rank reduces the counters of its own rows, and one gather brings its RGBA rows and its
+32-byte partial diagnostics to rank 0, which rebuilds the frame and combines the partial sums with ONE native
+kernel -- total work fixed, so scaling is "strong".
 
 Frames are independent, so `--frames-in-flight S` (default 12) enqueues consecutive frames on S HIP streams with
 S buffer sets: the tail of a frame's persistent kernel -- its slowest rays, ~0.3 ms during which most CUs idle --
 overlaps the following frames.  Every frame is still rendered, shaded and reduced in full; S = 1 is strictly serial.
-With frames in flight a launch uses one persistent workgroup per CU instead of four (the other frames' workgroups
-fill the CU) and the process asks the HIP runtime for sixteen hardware queues (GPU_MAX_HW_QUEUES, default four) so
-that the streams do not share queues.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- HBM: 12 B/pixel of mandatory output / render-kernel time (HIP events)
-  cpu_baseline -- the oracle (C restatement, kind "port") on the host cores, rank 0, N = 1 (the only leg that loads oracle/)
+Rank 0 prints ONE JSON line (contract in the task statement).  What each number is:
+  value / ms_per_step   K frames with S frames in flight / wall time of the timed region (max over ranks)
+  value_serial          the same frames strictly one after the other (S = 1), timed right after the timed region
+  setup_frames          untimed frames run BEFORE the W warm-up frames (one per stream: a stream's first launch creates
+                        its hardware queue); 0 when W >= S
+  roofline              the render kernel ALONE: achieved = algorithmic bytes per launch / kernel_ms, where kernel_ms
+                        is the mean duration of serial launches (HIP events on the launch stream); frac = achieved /
+                        peak.  The overlapped figure (bytes x launches / wall time) is `achieved_in_flight`.
+                        traffic = FETCH_SIZE + WRITE_SIZE per launch and valu = the instruction mix priced with the
+                        measured issue costs, both from profiles/r02/pmc_<workload>.json -- used only if that file was
+                        measured on the kernel sources now in the tree (source hash) with the options of this run.
+  cpu_baseline          the reference's policy on this box's host cores: oracle/rm_oracle.js (the JS restatement; the
+                        reference itself cannot run here) on node worker_threads, N = max(1, min(4, cores - 1)) workers,
+                        contiguous ceil(H/N)-row tiles, whole frames after a warm-up (main.ts:318,444-449), plus the C
+                        port on all cores.  The only leg that loads oracle/.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts: a hardware queue per stream in flight (default 4)
+# Before anything initialises HIP / HSA (ADVICE r1: set after torch.cuda.set_device these have no effect):
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")           # a hardware queue per stream in flight (default 4)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_PIXEL = 12  # depth 1 + normal 3 + sdfEval 2 + iters 2 + RGBA 4 (SURVEY 8d), ~0 read
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 WORKLOADS = {
     "C2": dict(name="C2: Grid of Spheres (9), 1920x1080, sphere-tracing + BVH, Phong shader",
@@ -65,25 +80,59 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(wl, budget_s=20.0):
-    """Oracle (C restatement of the reference's path) on this host's cores.  Bounded sample:
-    every `stride`-th row of the same frame, rows spread over a thread pool (ctypes drops
-    the GIL), scaled to frames/s; stride is chosen from a quick probe so the sample costs
-    about `budget_s` of CPU work."""
+def host_cores():
+    """Cores this process may use; 16 = the CPU share of a one-GPU box (the host itself reports every core of the node)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, os.cpu_count() or 1, aff))
+
+
+def kernel_source_hash():
+    """sha-256 (16 hex digits) of the kernel sources: a PMC file measured on other sources is stale."""
+    csrc = os.path.join(ROOT, "cpu_raymarcher_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload, options):
+    """profiles/r02/pmc_<workload>.json (scripts/profile_r02.sh + scripts/make_pmc_json.py), or (None, reason)."""
+    path = os.path.join(PROFILE_DIR, "pmc_%s.json" % workload)
+    try:
+        with open(path) as f:
+            pj = json.load(f)
+    except (OSError, ValueError):
+        return None, "no PMC file for this workload"
+    if pj.get("source_sha16") != kernel_source_hash():
+        return None, "stale: %s was measured on kernel sources %s, the tree holds %s" % (
+            os.path.relpath(path, ROOT), pj.get("source_sha16"), kernel_source_hash())
+    if {k: int(v) for k, v in pj.get("options", {}).items()} != {k: int(v) for k, v in options.items()}:
+        return None, "stale: %s was measured with options %s, this run uses %s" % (
+            os.path.relpath(path, ROOT), pj.get("options"), options)
+    return pj, os.path.relpath(path, ROOT)
+
+
+def cpu_baseline_port(wl, frames=5):
+    """The C port (oracle/rm_oracle.c) on all host cores: whole frames, one warm-up frame, rows handed out one at a
+    time to a thread pool (ctypes drops the GIL) -- dynamic row scheduling, i.e. better balanced than the reference's
+    contiguous tiles, so this is the stronger CPU number.  Frames are bounded to ~20 s of wall time."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     W, H = wl["width"], wl["height"]
     spheres = O.synthetic_spheres(wl["synthetic"]) if "synthetic" in wl else None
     prims = O.synthetic_mixed_prims(wl["mixed"]) if "mixed" in wl else None
     sc = O.OracleScene(preset=wl.get("preset"), accel=wl["accel"], spheres=spheres, prims=prims)
-    # 16 = the CPU share of a one-GPU box (the host itself reports every core of the node)
-    cores = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16))
+    cores = host_cores()
+    # probe: is a whole frame affordable?  Otherwise every stride-th row, spread over the whole frame, and say so.
     t0 = time.time()
     probe_rows = list(range(H // 64, H, H // 8))[:8]
     for y in probe_rows:
         sc.render(W, H, y, y + 1)
     per_row = (time.time() - t0) / len(probe_rows)
-    stride = max(1, int(per_row * H / budget_s + 0.999))
+    stride = max(1, int(per_row * H * (frames + 1) / cores / 20.0 + 0.999))
     rows = list(range(0, H, stride))
 
     def work(y):
@@ -91,54 +140,77 @@ def cpu_baseline(wl, budget_s=20.0):
         O.shade(wl["shader"], d, n, s, i, W, 1)
         return int(s.astype("int64").sum())
 
-    t0 = time.time()
+    times, total = [], 0
     with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(work, rows))
-    dt = time.time() - t0
+        sum(ex.map(work, rows))  # warm-up frame
+        for _ in range(frames):
+            t0 = time.time()
+            total = sum(ex.map(work, rows))
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     fps = 1.0 / (dt * H / len(rows))
+    what = ("%d whole %dx%d frames" % (frames, W, H)) if stride == 1 else \
+        ("%d passes over every %d-th row of the %dx%d frame (%d rows, spread over the whole frame), scaled by H/rows"
+         % (frames, stride, W, H, len(rows)))
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "every %d-th row of the %dx%d frame (%d rows, %.1f s wall on %d threads), oracle/rm_oracle.c "
-                      "render + shade, scaled by H/rows" % (stride, W, H, len(rows), dt, cores),
+            "sample": "%s after one warm-up pass, %.2f s each on %d threads, rows scheduled dynamically; oracle/rm_oracle.c "
+                      "render + shade" % (what, dt, cores),
             "sample_avg_sdf_calls_per_pixel": total / (len(rows) * W)}
 
 
-def js_engine_baseline(wl, rows=32):
-    """The JS restatement (oracle/rm_oracle.js) on this host's node, one thread, on a band of `rows`
-    rows in the middle of the frame: what the reference's own language runtime does per worker.
-    Returns None when node is absent or the workload has no JS description (synthetic scenes)."""
+def cpu_baseline_js_pool(wl, frames=5, budget_s=25.0):
+    """The reference's own policy (main.ts:318,444-449) with the JS restatement on this host's node: worker_threads,
+    N = max(1, min(4, cores - 1)) workers, contiguous ceil(H/N)-row tiles, scene rebuilt per job, tiles transferred
+    back, shade + diagnostics on the main thread; `frames` frames timed after one warm-up.  Bounded: when whole frames
+    would exceed ~budget_s, every k-th row of every tile is rendered (spread over the whole frame) and the time scaled
+    by k -- stated in `sample`.  None when node is absent or the workload has no JS description (synthetic scenes)."""
     import shutil
-    import subprocess
     import tempfile
     if shutil.which("node") is None or "preset" not in wl:
         return None
     W, H = wl["width"], wl["height"]
-    y0 = H // 2 - rows // 2
-    cfg = dict(preset=wl["preset"], accel=wl["accel"], width=W, height=H, shader=wl["shader"], yStart=y0, yEnd=y0 + rows)
-    with tempfile.TemporaryDirectory() as td:
-        with open(os.path.join(td, "cfg.json"), "w") as f:
-            json.dump(cfg, f)
-        try:
-            out = subprocess.check_output(["node", os.path.join(ROOT, "oracle", "rm_oracle.js"), "render",
-                                           os.path.join(td, "cfg.json"), os.path.join(td, "out")], timeout=120)
-            st = json.loads(out)
-        except Exception:
-            return None
-    ms = st.get("render_ms")
-    if not ms:
-        return None
-    return {"value": 1.0 / (ms * 1e-3 * H / rows), "unit": "frames/s", "threads": 1, "engine": st.get("engine"),
-            "sample": "rows [%d,%d) of the %dx%d frame in %.0f ms, scaled by H/rows; the reference runs "
-                      "min(4, cores-1) such workers (main.ts:318)" % (y0, y0 + rows, W, H, ms)}
+    cores = host_cores()
+    n_workers = max(1, min(4, cores - 1))
+    js = os.path.join(ROOT, "oracle", "rm_oracle.js")
+
+    def run(cfg, timeout):
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "cfg.json"), "w") as f:
+                json.dump(cfg, f)
+            return json.loads(subprocess.check_output(["node", js, "pool", os.path.join(td, "cfg.json")], timeout=timeout))
+
+    base = dict(preset=wl["preset"], accel=wl["accel"], width=W, height=H, shader=wl["shader"], cores=cores, workers=n_workers)
+    try:
+        probe = run(dict(base, frames=1, rowStride=64), 300)  # ~1.5 % of the rows: how long would a frame take?
+        frame_s = probe["frame_ms"][0] * 1e-3 * 64
+        k = max(1, int(frame_s * (frames + 1) / budget_s + 0.999))
+        res = run(dict(base, frames=frames, rowStride=k), 600)
+    except Exception as e:  # noqa: BLE001 -- a baseline leg must not take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    ms = sum(res["frame_ms"]) / len(res["frame_ms"])
+    scale = H / res["sampled_rows"]
+    return {"value": 1.0 / (ms * 1e-3 * scale), "unit": "frames/s", "cores": cores, "workers": n_workers,
+            "kind": "port (JS restatement under the reference's worker policy)", "engine": res.get("engine"),
+            "frame_ms_sampled": res["frame_ms"],
+            "sample": ("%d whole frames" % frames if k == 1 else
+                       "%d frames of every %d-th row of every worker's contiguous tile (%d of %d rows, spread over the "
+                       "whole frame), time scaled by H/rows" % (frames, k, res["sampled_rows"], H)) +
+                      " after one warm-up frame; N = max(1, min(4, cores - 1)) = %d worker_threads, ceil(H/N)-row tiles, "
+                      "scene rebuilt per job, shade + diagnostics on the main thread (main.ts:318,444-449,493-548)" % n_workers,
+            "sample_avg_sdf_calls_per_pixel": res["diagnostics"]["sum_sdf"] / (res["sampled_rows"] * W)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)   # eight rounds of the twelve frames in flight: ramp-up and drain are
-    ap.add_argument("--warmup", type=int, default=16)  # ~3 % of the timed region (20 steps: 783 frames/s, 96 steps: 808)
+    ap.add_argument("--warmup", type=int, default=16)  # ~3 % of the timed region
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--partition", default="interleaved", choices=["interleaved", "contiguous"])
     ap.add_argument("--stripe", type=int, default=16)
+    ap.add_argument("--root-share", default="auto",
+                    help="N > 1: rank 0's stripe share relative to the other ranks' (1.0 = equal deal), or 'auto': measured "
+                         "before the warm-up (rank 0's reassembly + an equal shard's render time, no collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analytics-sweep", action="store_true",
                     help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
@@ -177,7 +249,6 @@ def main():
     dev = torch.device("cuda", dev_index)
     coll = dist
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -203,27 +274,29 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     ctx = R.Context(dev_index)
+    user_opts = {}
     for kv in args.opt:
         k, v = kv.split("=")
+        user_opts[k] = int(v)
         ctx.set_option(k, int(v))
     # With frames in flight a launch runs best with few persistent workgroups (one per CU): the other frames' workgroups
-    # fill the CUs, and each workgroup stages the scene tables once for four times as many tiles.  Measured on the final
-    # kernel (scripts/bench_variants.sh, scripts/overlap_probe.py): whole frame 858 (one per CU), 841 (two), 825 (three)
-    # frames/s; the 1/8-row shard of an 8-GPU job 0.22 (one) against 0.26 ms (two) per frame.  The static tile share
-    # (option `static`) lost to this setting and is no longer used here.
-    in_flight_bpc = None
-    in_flight_opts = {}  # option -> (value with frames in flight, library default restored for the launch measured alone)
-    if max(1, args.frames_in_flight) > 1:
-        in_flight_opts["blocks_per_cu"] = (1, 4)  # final kernel: one per CU 858, two 841 frames/s; 1/8-row shard 0.22 against 0.26 ms
-        if world == 1:  # whole frames: 256-pixel work items of 8 x 32 pixels (744 -> 763 frames/s; alone 2.00 -> 2.24 ms)
-            in_flight_opts["item_px"] = (256, 128)
-            in_flight_opts["tile_w"] = (8, 16)
+    # fill the CUs, and each workgroup stages the scene tables once for four times as many tiles.
+    S = max(1, args.frames_in_flight)
+    in_flight_opts = {}  # option -> (value with frames in flight, library default used by serial launches)
+    if S > 1:
+        in_flight_opts["blocks_per_cu"] = (1, ctx.get_option("blocks_per_cu"))
+        if world == 1:  # whole frames: 256-pixel work items of 8 x 32 pixels
+            in_flight_opts["item_px"] = (256, ctx.get_option("item_px"))
+            in_flight_opts["tile_w"] = (8, ctx.get_option("tile_w"))
         for k in list(in_flight_opts):
-            if any(kv.startswith(k + "=") for kv in args.opt):
+            if k in user_opts:
                 del in_flight_opts[k]
-        for k, (v, _) in in_flight_opts.items():
-            ctx.set_option(k, v)
-        in_flight_bpc = in_flight_opts.get("blocks_per_cu", (None, None))[0]
+
+    def apply_opts(in_flight):
+        for k, (v, dflt) in in_flight_opts.items():
+            ctx.set_option(k, v if in_flight else dflt)
+
+    apply_opts(True)
     scene = R.Scene(wl["accel"], ctx=ctx)
     if "synthetic" in wl:
         from cpu_raymarcher_amd.synthetic import synthetic_spheres  # SURVEY 8(d) C5 definition
@@ -236,23 +309,21 @@ def main():
         scene.loadPreset(wl["preset"])
     tracer = R.SphereTracer()
     u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)  # noqa: E731
+    i16 = lambda n: torch.zeros(n, dtype=torch.int16, device=dev)  # noqa: E731
     acc = torch.zeros(4, dtype=torch.int64, device=dev)
     ev_pairs = []
+    root_balance = None
 
-    S = max(1, args.frames_in_flight)
     # (the analytics sweep keeps frames in flight too: every frame has its own camera, launch parameters and
     # accumulator, and the per-frame series is read in frame order after the timed region)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     if world == 1:
         sets = []
         for _ in range(S):
-            sets.append(dict(depth=u8(W * H), normal=u8(3 * W * H), rgba=u8(4 * W * H),
-                             sdf=torch.zeros(W * H, dtype=torch.int16, device=dev),
-                             iters=torch.zeros(W * H, dtype=torch.int16, device=dev),
+            sets.append(dict(depth=u8(W * H), normal=u8(3 * W * H), rgba=u8(4 * W * H), sdf=i16(W * H), iters=i16(W * H),
                              acc=torch.zeros(4, dtype=torch.int64, device=dev)))
         acc = sets[0]["acc"]
         frame_no = [0]
-
         series = []  # analytics sweep: one accumulator per frame, read after the timed region
 
         def step(timed):
@@ -282,10 +353,64 @@ def main():
         # Only RGBA travels (north_star: "RCCL gather ... of the per-tile RGBA buffers").  The per-pixel counters stay on
         # the rank that produced them: each rank reduces its own rows (main.ts:528-548 is a sum / max / min, so partial
         # results combine exactly) into a 32-byte accumulator in the tail of its packed buffer, which rides along in the
-        # same gather; rank 0 combines the N partial accumulators per frame.
-        gather_counters = args.partition != "interleaved"  # the per-range fallback path keeps the three-section gather
+        # same gather; rank 0 combines the N partial accumulators inside the kernel that rebuilds the frame.
+        gather_counters = args.partition != "interleaved"  # the reference's contiguous partition keeps the three-section gather
         sections = ("rgba", "sdf", "iters") if gather_counters else ("rgba",)
-        layout = D.FrameLayout(W, H, world, sections, args.partition, args.stripe, tail=0 if gather_counters else 32)
+        nbuf = max(2, S)
+
+        def make_layout(weights):
+            return D.FrameLayout(W, H, world, sections, args.partition, args.stripe, tail=0 if gather_counters else 32,
+                                 weights=weights)
+
+        # ---- rank 0's share.  Rank 0 renders its stripes AND rebuilds the frame (and runs the receiving side of the
+        # gather); with an equal deal it is the slowest rank and sets the frame rate.  'auto' measures, with
+        # no collective involved, (a) an equal shard's render + reduce and (b) the same plus rank 0's reassembly, both
+        # with S frames in flight, and deals rank 0 the share that equalises the ranks (distributed.balanced_weights).
+        weights = None
+        if args.partition == "interleaved":
+            if args.root_share != "auto":
+                weights = [max(1, int(round(1000 * float(args.root_share))))] + [1000] * (world - 1)
+                root_balance = {"mode": "given", "weights": weights}
+            else:
+                lay0 = make_layout(None)
+                cal_sets = [dict(p=u8(lay0.nbytes), sdf=i16(lay0.cap * W), iters=i16(lay0.cap * W)) for _ in range(nbuf)]
+                cal_px = W * sum(b - a for a, b in lay0.rows(rank))
+                cal_asm = D.GpuFrameAssembler(lay0, dev, nbuf, ctx=ctx) if rank == 0 else None
+                cal_acc = torch.zeros(4, dtype=torch.int64, device=dev)
+
+                ra_extra = [None]  # the buffer set of the frame being enqueued: its rank-local sdfEval / iters
+                ra = D.gpu_render_all(ctx, scene, W, H, wl["shader"], lay0, rank, extra=lambda packed: ra_extra[0])
+
+                def cal_frames(n, with_asm):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for f in range(n):
+                        k = f % nbuf
+                        b = cal_sets[k]
+                        with torch.cuda.stream(streams[k % S]):
+                            ra_extra[0] = b
+                            ra(b["p"])
+                            tail = b["p"][lay0.tail_offset:lay0.tail_offset + 32].view(torch.int64)
+                            ctx.reduce_counters_enqueue(b["sdf"][:cal_px], b["iters"][:cal_px], tail)
+                            if with_asm:
+                                cal_asm.assemble(k, cal_acc)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / n
+
+                cal_frames(2 * nbuf, rank == 0)
+                t_shard = cal_frames(4 * nbuf, False)
+                t_root = cal_frames(4 * nbuf, True) if rank == 0 else 0.0
+                t = torch.tensor([t_shard, t_root], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                tl = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(tl, t)
+                shard = sum(float(x[0]) for x in tl) / world
+                over = max(0.0, float(tl[0][1]) - float(tl[0][0]))
+                weights = D.balanced_weights(world, over, shard)
+                root_balance = {"mode": "auto", "weights": weights, "equal_shard_ms": 1e3 * shard,
+                                "root_reassembly_ms": 1e3 * over,
+                                "note": "measured before the warm-up without collectives, %d frames in flight" % S}
+                del cal_sets, cal_asm
+        layout = make_layout(weights)
         render_rows = D.gpu_render_rows(ctx, scene, W, H, wl["shader"], layout)
         timed_flag = [False]
         my_px = W * sum(b - a for a, b in layout.rows(rank))
@@ -294,31 +419,26 @@ def main():
         def extra(packed):
             key = packed.data_ptr()
             if key not in local_counters:
-                local_counters[key] = {"sdf": torch.zeros(layout.cap * W, dtype=torch.int16, device=dev),
-                                       "iters": torch.zeros(layout.cap * W, dtype=torch.int16, device=dev)}
+                local_counters[key] = {"sdf": i16(layout.cap * W), "iters": i16(layout.cap * W)}
             return local_counters[key]
 
-        def timed_render_rows(a, b, local, packed):
+        def timed_call(fn, *a):
             if timed_flag[0]:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                render_rows(a, b, local, packed)
+                fn(*a)
                 e1.record()
                 ev_pairs.append((e0, e1))
             else:
-                render_rows(a, b, local, packed)
+                fn(*a)
+
+        def timed_render_rows(a, b, local, packed):
+            timed_call(render_rows, a, b, local, packed)
 
         render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank, extra=None if gather_counters else extra)
 
         def timed_render_all(packed):
-            if timed_flag[0]:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                render_all(packed)
-                e1.record()
-                ev_pairs.append((e0, e1))
-            else:
-                render_all(packed)
+            timed_call(render_all, packed)
             if not gather_counters:  # this rank's partial diagnostics, into the tail that travels with the gather
                 c = extra(packed)
                 tail = packed[layout.tail_offset:layout.tail_offset + 32].view(torch.int64)
@@ -326,27 +446,22 @@ def main():
 
         shr = D.ShardedFrameRenderer(layout, rank, world, timed_render_rows, u8, coll,
                                      render_all=timed_render_all if render_all else None,
-                                     frames_in_flight=max(2, S), streams=streams if S > 1 else None)
-        # rank 0 reassembly: one indexed row-gather per section (D.GpuFrameAssembler)
+                                     frames_in_flight=nbuf, streams=streams if S > 1 else None)
         asm = None
         if rank == 0:
-            asm = D.GpuFrameAssembler(layout, dev, shr.nbuf)
+            asm = D.GpuFrameAssembler(layout, dev, shr.nbuf, ctx=ctx)
             shr.recv = asm.gather_lists()
-
-        # one accumulator per buffer set: reductions of different frames run concurrently on different streams
+        # one accumulator per buffer set: frames in flight run concurrently on different streams
         accs = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(shr.nbuf)]
         acc = accs[0]
-        lo32 = torch.tensor(0xFFFFFFFF, dtype=torch.int64, device=dev)
 
         def assemble(slot):
             with shr.on_stream(slot):
-                frame = asm.assemble(slot)
                 if gather_counters:
+                    frame = asm.assemble(slot)
                     ctx.reduce_counters_enqueue(frame["sdf"].view(torch.int16), frame["iters"].view(torch.int16), accs[slot])
-                else:  # combine the ranks' partial accumulators: sums, max of the low word, min of the high word
-                    part = asm.recv2d[slot][:, layout.tail_offset:layout.tail_offset + 32].view(torch.int64)
-                    torch.sum(part[:, :2], dim=0, out=accs[slot][:2])
-                    accs[slot][2] = torch.amax(part[:, 2] & lo32) | (torch.amin(part[:, 2] >> 32) << 32)
+                else:  # one kernel: stripes -> frame, partial accumulators -> accs[slot]
+                    asm.assemble(slot, accs[slot])
 
         pending = []
 
@@ -374,8 +489,10 @@ def main():
 
     # Set-up, not a step: every stream's first launch creates its hardware queue and touches its buffer set (tens of
     # milliseconds each).  With fewer warm-up steps than streams that cost would land in the timed region, so each
-    # stream is used once here; the W warm-up steps follow.
+    # stream is used once here (reported as setup_frames); the W warm-up steps follow.
+    setup_frames = 0
     if S > args.warmup:
+        setup_frames = S
         for _ in range(S):
             step(False)
         finish()
@@ -394,10 +511,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kernel_in_flight = ctx.last_kernel()
 
-    # dominant kernel: the render kernel.  Average launch duration from the HIP events recorded
-    # on the launch stream; per launch this rank rendered rows_launched / launches pixels-rows.
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    # dominant kernel: the render kernel.  kern_ms_in_flight = mean launch duration inside the timed region (HIP events
+    # on the launch stream; with S > 1 it spans the other frames' work too).
+    kern_ms_in_flight = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
     n_launches = len(ev_pairs)
     if world == 1:
         px_per_launch = W * H
@@ -405,18 +523,17 @@ def main():
         rows_mine = layout.rows(rank)
         launches = 1 if args.partition == "interleaved" else max(1, len(rows_mine))
         px_per_launch = W * sum(b - a for a, b in rows_mine) / launches
-    # With several frames in flight the launches overlap: a launch's own duration (kern_ms) then spans the other
-    # frames' work as well, and bytes / duration would under-count by the overlap factor.  The device-level figure
-    # is bytes per launch x launches / wall time of the timed region; the launch duration of the kernel running
-    # alone is measured right after the timed region (serial launches, HIP events on the launch stream).
-    kern_serial_ms = kern_ms
-    if S > 1 and world == 1:
-        ser = []
+    bytes_per_launch = ALG_BYTES_PER_PIXEL * px_per_launch
+
+    # The launch running ALONE (library defaults, serial, HIP events around each launch) and the strictly serial frame
+    # rate (render + reduce back to back on one stream), both right after the timed region.  N = 1 only.
+    kern_ms, value_serial, kernel_alone = kern_ms_in_flight, None, kernel_in_flight
+    if world == 1 and not args.analytics_sweep:
         b = sets[0]
-        for k, (_, dflt) in in_flight_opts.items():
-            ctx.set_option(k, dflt)  # the launch running alone uses the library defaults
+        apply_opts(False)
+        ser = []
         with torch.cuda.stream(streams[0]):
-            for _ in range(5):
+            for _ in range(2 + 6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0,
@@ -424,27 +541,33 @@ def main():
                 e1.record()
                 ser.append((e0, e1))
                 torch.cuda.synchronize()
-        kern_serial_ms = sum(a.elapsed_time(c) for a, c in ser) / len(ser)
-        for k, (v, _) in in_flight_opts.items():
-            ctx.set_option(k, v)
-    bytes_per_launch = ALG_BYTES_PER_PIXEL * px_per_launch
-    if S > 1:
-        achieved = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
-    else:
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    achieved_serial = bytes_per_launch / (kern_serial_ms * 1e-3) / 1e9 if kern_serial_ms > 0 else 0.0
+            kernel_alone = ctx.last_kernel()
+            kern_ms = sum(a.elapsed_time(c) for a, c in ser[2:]) / len(ser[2:])
+            n_ser = max(5, min(20, args.steps))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_ser):
+                tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0,
+                                     shadedBuffer=b["rgba"], shader=wl["shader"])
+                ctx.reduce_counters_enqueue(b["sdf"], b["iters"], b["acc"])
+            torch.cuda.synchronize()
+            value_serial = n_ser / (time.perf_counter() - t0)
+        apply_opts(True)
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    achieved_in_flight = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-    # the per-launch figure measured with rocprofv3 for this workload is taken from the committed
-    # profile (profiles/r01/traffic.json, which names its source), at N = 1 only.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-            tj = json.load(f)
-        if world == 1 and args.workload in tj and not args.opt:
-            traffic = tj[args.workload]["bytes"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    # HBM traffic and the VALU mix of the dominant kernel: PMC counters cannot be read from inside this process; the
+    # per-launch figures come from profiles/r02/pmc_<workload>.json, which scripts/profile_r02.sh measured with rocprofv3
+    # on serial launches (library defaults) -- used only if measured on the sources now in the tree, N = 1.
+    traffic, valu, pmc_note = None, None, None
+    if world == 1:
+        pj, pmc_note = load_pmc(args.workload, user_opts)
+        if pj:
+            traffic = pj.get("traffic_bytes")
+            valu = pj.get("valu")
+            if valu and valu.get("weighted_issue_floor_ms") and kern_ms > 0:
+                valu = dict(valu, frac=valu["weighted_issue_floor_ms"] / kern_ms,
+                            frac_in_flight=valu["weighted_issue_floor_ms"] / (1e3 * elapsed / args.steps))
 
     if rank == 0:
         d = ctx.decode_acc(acc)
@@ -458,28 +581,31 @@ def main():
             "config": {"workload": wl["name"], "width": W, "height": H, "acceleration_structure": wl["accel"],
                        "shader": wl["shader"], "camera": {"pitch": 0.0, "yaw": 0.0}, "frames_in_flight": S,
                        "parallelism": "1 GPU" if world == 1 else
-                       "row-tile shard x%d (%s, stripe %d) + RCCL gather of RGBA and per-rank diagnostics sums to rank 0"
-                       % (world, args.partition, args.stripe)},
+                       "row-tile shard x%d (%s, stripe %d, rank-0 share weighted) + RCCL gather of RGBA and per-rank "
+                       "diagnostics sums to rank 0" % (world, args.partition, args.stripe)},
+            "setup_frames": setup_frames, "value_serial": value_serial,
             "avg_sdf_calls_per_pixel": d["total_sdf"] / (W * H), "avg_iterations_per_pixel": d["total_iters"] / (W * H),
             "max_sdf_calls": d["max_sdf"], "min_sdf_calls": d["min_sdf"],
             "sphere_evals_per_s": d["total_sdf"] * fps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01/traffic.json"
-                         if traffic else None,
-                         "kernel": "render_kernel_v2<2, true, true, false>" if args.workload == "C3" else "render kernel",
-                         "kernel_ms": kern_serial_ms, "kernel_ms_in_flight": kern_ms, "frames_in_flight": S,
-                         "persistent_workgroups_per_cu": in_flight_bpc or 4,
-                         "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},
-                         "achieved_one_launch_alone": achieved_serial,
-                         "basis": ("device level: algorithmic bytes per launch x %d launches / wall time of the timed "
-                                   "region (%d frames in flight overlap; kernel_ms is the launch running alone, "
-                                   "kernel_ms_in_flight the mean overlapped launch)" % (n_launches, S)) if S > 1 else
-                                  "algorithmic bytes per launch / mean launch duration (HIP events, timed region)",
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "FP64-VALU/divergence bound, not HBM bound: 12 B/pixel out, ~1e3 FP64 ops/pixel "
-                                 "(DESIGN.md)"},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "pmc_source": pmc_note,
+                         "kernel": kernel_alone, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "basis": "the launch ALONE: algorithmic bytes per launch / mean duration of %s (HIP events on the "
+                                  "launch stream)" % ("serial launches with the library's default options, right after the "
+                                                      "timed region" if world == 1 and not args.analytics_sweep else
+                                                      "the timed region's launches"),
+                         "achieved_in_flight": achieved_in_flight, "frac_in_flight": achieved_in_flight / HBM_PEAK_GBPS,
+                         "kernel_in_flight": kernel_in_flight, "kernel_ms_in_flight": kern_ms_in_flight,
+                         "frames_in_flight": S, "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},
+                         "basis_in_flight": "device level: algorithmic bytes per launch x %d launches / wall time of the "
+                                            "timed region (launches overlap)" % n_launches,
+                         "valu": valu,
+                         "note": "FP64-VALU issue / divergence bound, not HBM bound: 12 B/pixel out, ~6e3 lane-instructions "
+                                 "per pixel; `valu` prices the measured instruction mix with the measured issue costs "
+                                 "(DESIGN.md 4)"},
         }
+        if root_balance:
+            out["config"]["root_balance"] = root_balance
         if world > 1:
             # outside the timed region: the gathered, reassembled frame must equal this frame
             # rendered whole on rank 0's GPU, byte for byte
@@ -498,10 +624,10 @@ def main():
                  "avg_iterations": ctx.decode_acc(a)["total_iters"] / (W * H), "max_sdf_calls": ctx.decode_acc(a)["max_sdf"],
                  ("frame_ms" if S == 1 else "frame_ms_overlapped"): e0.elapsed_time(e1)} for (y, a), (e0, e1) in zip(series, ev_pairs)]
         if world == 1 and not args.no_cpu_baseline and not args.analytics_sweep:
-            out["cpu_baseline"] = cpu_baseline(wl)
-            js = js_engine_baseline(wl)
+            out["cpu_baseline"] = cpu_baseline_port(wl)
+            js = cpu_baseline_js_pool(wl)
             if js:
-                out["cpu_baseline"]["js_engine_single_thread"] = js
+                out["cpu_baseline"]["reference_policy_js"] = js
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)

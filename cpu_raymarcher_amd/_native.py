@@ -73,6 +73,7 @@ SIGNATURES = {
     "rm_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "rm_destroy": (None, [_VP]),
     "rm_last_error": (C.c_char_p, [_VP]),
+    "rm_last_kernel": (C.c_char_p, [_VP]),
     "rm_version": (C.c_char_p, []),
     "rm_algorithm_from_string": (C.c_int, [C.c_char_p]),
     "rm_accel_from_string": (C.c_int, [C.c_char_p]),
@@ -94,6 +95,11 @@ SIGNATURES = {
     "rm_render_stripes_device": (C.c_int, [_VP, C.POINTER(rm_job), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            _VP, _VP, _VP, _VP, _VP, _VP]),
     "rm_stripe_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rm_deal_stripes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
+    "rm_render_stripe_list_device": (C.c_int, [_VP, C.POINTER(rm_job), C.c_int32, C.c_int32, _VP, C.c_int32,
+                                               _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rm_assemble_frame_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _VP,
+                                           C.c_int32, C.c_int32, _VP, C.c_int64, _VP, _VP]),
     "rm_shade": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP]),
     "rm_shade_device": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rm_reduce_counters": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics)]),
@@ -119,7 +125,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
-    cmd = ["make", "-C", CSRC, "all"] + (["-B"] if force else [])
+    cmd = ["make", "-j%d" % min(8, os.cpu_count() or 1), "-C", CSRC, "all"] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 

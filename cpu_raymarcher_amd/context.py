@@ -19,6 +19,42 @@ def _ptr(x):
     return x.ctypes.data_as(C.c_void_p)
 
 
+_BPP = {"depth": 1, "normal": 3, "sdf": 2, "iters": 2, "rgba": 4}
+
+
+def _check_buffers(npx, bufs, need_device=None):
+    """The C ABI takes raw pointers: everything it assumes about a buffer is checked here.  bufs: name -> buffer
+    or None.  Every buffer must be C-contiguous, of the reference's element size (depth / normal / rgba 1 byte, sdf / iters
+    2 bytes: Uint8ClampedArray / Uint16Array) and hold at least npx pixels; all of them on the host or all on one
+    device.  Returns True when they are device (torch CUDA) buffers."""
+    on_dev = None
+    for name, b in bufs.items():
+        if b is None:
+            continue
+        esz = 2 if name in ("sdf", "iters") else 1
+        if _is_torch(b):
+            dev, contiguous, itemsize, nbytes = b.is_cuda, b.is_contiguous(), b.element_size(), b.numel() * b.element_size()
+        elif isinstance(b, np.ndarray):
+            dev, contiguous, itemsize, nbytes = False, b.flags["C_CONTIGUOUS"], b.itemsize, b.nbytes
+            if not b.flags["WRITEABLE"] and name != "_in":
+                raise ValueError("%s buffer is read-only" % name)
+        else:
+            raise ValueError("%s must be a numpy array or a torch tensor, not %s" % (name, type(b).__name__))
+        if not contiguous:
+            raise ValueError("%s buffer must be C-contiguous" % name)
+        if itemsize != esz:
+            raise ValueError("%s buffer must have %d-byte elements (got %d)" % (name, esz, itemsize))
+        if nbytes < npx * _BPP[name]:
+            raise ValueError("%s buffer holds %d bytes, the tile needs %d" % (name, nbytes, npx * _BPP[name]))
+        if on_dev is None:
+            on_dev = dev
+        elif on_dev != dev:
+            raise ValueError("buffers must be all on the host or all on the device")
+    if need_device is not None and on_dev is not None and on_dev != need_device:
+        raise ValueError("this entry point takes %s buffers" % ("device" if need_device else "host"))
+    return bool(on_dev)
+
+
 def _current_stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -130,29 +166,77 @@ class Context:
     def render_tile(self, job, depth, normal, sdf, iters, rgba=None, shader=0):
         """Host numpy buffers -> rm_render_tile (+ rm_shade when rgba is given); torch CUDA
         tensors -> rm_render_tile_device on torch's current stream (fused shade)."""
-        bufs = [b for b in (depth, normal, sdf, iters, rgba) if b is not None]
-        if bufs and all(_is_torch(b) for b in bufs):
-            for b in bufs:
-                if not b.is_cuda or not b.is_contiguous():
-                    raise ValueError("device buffers must be contiguous CUDA tensors")
+        npx = max(0, job.y_end - job.y_start) * max(0, job.width)
+        bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
+        if _check_buffers(npx, bufs):
+            self._same_device(bufs)
             N.check(self._h, N.lib().rm_render_tile_device(
                 self._h, C.byref(job), int(shader), _ptr(depth), _ptr(normal), _ptr(sdf), _ptr(iters),
                 _ptr(rgba), _current_stream_ptr()))
             return
+        if depth is None or normal is None or sdf is None or iters is None:
+            raise ValueError("the host entry point needs all four G-buffers")
         N.check(self._h, N.lib().rm_render_tile(self._h, C.byref(job), _ptr(depth), _ptr(normal),
                                                  _ptr(sdf), _ptr(iters)))
         if rgba is not None:
             rows = max(0, job.y_end - job.y_start)
             self.shade(shader, job.width, rows, depth, normal, sdf, iters, rgba)
 
+    def _same_device(self, bufs):
+        for name, b in bufs.items():
+            if b is not None and _is_torch(b) and b.is_cuda and b.device.index != self.device:
+                raise ValueError("%s buffer is on cuda:%s, the context on cuda:%d" % (name, b.device.index, self.device))
+
     def render_stripes(self, job, stripe_rows, n_parts, part, depth, normal, sdf, iters, rgba=None, shader=0):
         """One launch for every stripe of `part` (rm_render_stripes_device); device buffers only."""
+        rows = N.lib().rm_stripe_rows(job.y_start, job.y_end, int(stripe_rows), int(n_parts), int(part))
+        if rows < 0:
+            raise ValueError("bad stripe partition")
+        bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
+        _check_buffers(rows * max(0, job.width), bufs, need_device=True)
+        self._same_device(bufs)
         N.check(self._h, N.lib().rm_render_stripes_device(
             self._h, C.byref(job), int(shader), int(stripe_rows), int(n_parts), int(part), _ptr(depth), _ptr(normal),
             _ptr(sdf), _ptr(iters), _ptr(rgba), _current_stream_ptr()))
 
+    def render_stripe_list(self, job, stripe_rows, stripe_ids, depth, normal, sdf, iters, rgba=None, shader=0):
+        """One launch for the listed stripes (strictly increasing ids; rm_render_stripe_list_device), packed in list
+        order; device buffers only.  Serves any deal of stripes to ranks (deal_stripes)."""
+        ids = np.ascontiguousarray(stripe_ids, dtype=np.int32)
+        height = max(0, job.y_end - job.y_start)
+        rows = sum(min(height, (int(i) + 1) * stripe_rows) - int(i) * stripe_rows for i in ids)
+        bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
+        _check_buffers(max(0, rows) * max(0, job.width), bufs, need_device=True)
+        self._same_device(bufs)
+        N.check(self._h, N.lib().rm_render_stripe_list_device(
+            self._h, C.byref(job), int(shader), int(stripe_rows), _ptr(ids), len(ids), _ptr(depth), _ptr(normal),
+            _ptr(sdf), _ptr(iters), _ptr(rgba), _current_stream_ptr()))
+
+    def assemble_frame(self, gathered, rank_stride, section_offset, row_bytes, height, stripe_rows, owner, world, frame,
+                       acc_offset=-1, acc=None):
+        """Rank 0's fan-in in one kernel (rm_assemble_frame_device): stripes of the gathered per-rank buffers -> row-major
+        frame, and the ranks' 32-byte partial diagnostics (at acc_offset of each rank's buffer) -> acc."""
+        own = np.ascontiguousarray(owner, dtype=np.int32)
+        for name, t, need in (("gathered", gathered, world * rank_stride), ("frame", frame, row_bytes * height)):
+            if not (_is_torch(t) and t.is_cuda and t.is_contiguous()) or t.numel() * t.element_size() < need:
+                raise ValueError("%s must be a contiguous CUDA tensor of at least %d bytes" % (name, need))
+        if acc is not None and (not (_is_torch(acc) and acc.is_cuda) or acc.numel() * acc.element_size() < 32):
+            raise ValueError("acc must be a CUDA tensor of 32 bytes")
+        N.check(self._h, N.lib().rm_assemble_frame_device(
+            self._h, _ptr(gathered), int(rank_stride), int(section_offset), int(row_bytes), int(height), int(stripe_rows),
+            _ptr(own), len(own), int(world), _ptr(frame), int(acc_offset), _ptr(acc), _current_stream_ptr()))
+
+    def last_kernel(self):
+        """The render-kernel instantiation the last render entry launched (rm_last_kernel)."""
+        return N.lib().rm_last_kernel(self._h).decode()
+
     def shade(self, shader, width, height, depth, normal, sdf, iters, rgba):
-        if _is_torch(rgba):
+        npx = max(0, int(width)) * max(0, int(height))
+        bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
+        if any(b is None for b in bufs.values()):
+            raise ValueError("shade needs all five buffers")
+        if _check_buffers(npx, bufs):
+            self._same_device(bufs)
             N.check(self._h, N.lib().rm_shade_device(self._h, int(shader), width, height, _ptr(depth),
                                                       _ptr(normal), _ptr(sdf), _ptr(iters), _ptr(rgba),
                                                       _current_stream_ptr()))
@@ -160,10 +244,22 @@ class Context:
             N.check(self._h, N.lib().rm_shade(self._h, int(shader), width, height, _ptr(depth), _ptr(normal),
                                                _ptr(sdf), _ptr(iters), _ptr(rgba)))
 
+    def _check_counters(self, sdf, iters):
+        if sdf is None or iters is None:
+            raise ValueError("null counter buffer")
+        n = int(sdf.numel()) if _is_torch(sdf) else int(sdf.size)
+        m = int(iters.numel()) if _is_torch(iters) else int(iters.size)
+        if n != m:
+            raise ValueError("sdfEval and iters differ in length (%d, %d)" % (n, m))
+        dev = _check_buffers(n, dict(sdf=sdf, iters=iters))
+        if dev:
+            self._same_device(dict(sdf=sdf, iters=iters))
+        return n, dev
+
     def reduce_counters(self, sdf, iters):
         out = N.rm_diagnostics()
-        n = int(sdf.numel()) if _is_torch(sdf) else int(sdf.size)
-        if _is_torch(sdf):
+        n, dev = self._check_counters(sdf, iters)
+        if dev:
             N.check(self._h, N.lib().rm_reduce_counters_device(self._h, _ptr(sdf), _ptr(iters), n,
                                                                 C.byref(out), _current_stream_ptr()))
         else:
@@ -175,7 +271,12 @@ class Context:
     def reduce_counters_enqueue(self, sdf, iters, acc):
         """Async diagnostics for a frame loop: `acc` is a CUDA int64[4] tensor that receives
         (total_sdf, total_iters, max_sdf | min_sdf << 32, pad); read it with decode_acc()."""
-        N.check(self._h, N.lib().rm_reduce_counters_enqueue(self._h, _ptr(sdf), _ptr(iters), int(sdf.numel()),
+        n, dev = self._check_counters(sdf, iters)
+        if not dev and n:
+            raise ValueError("reduce_counters_enqueue takes device buffers")
+        if not (_is_torch(acc) and acc.is_cuda and acc.numel() * acc.element_size() >= 32):
+            raise ValueError("acc must be a CUDA tensor of 32 bytes")
+        N.check(self._h, N.lib().rm_reduce_counters_enqueue(self._h, _ptr(sdf), _ptr(iters), n,
                                                             _ptr(acc), _current_stream_ptr()))
 
     @staticmethod
@@ -238,6 +339,19 @@ def camera_from_angles(pitch, yaw):
     if rc != N.RM_OK:
         raise N.RmError(rc, "rm_camera_from_angles")
     return rot, org
+
+
+def deal_stripes(rows, stripe_rows, n_parts, weights=None):
+    """rm_deal_stripes: owner of every stripe of `rows` rows (smooth weighted round-robin; equal weights = round-robin)."""
+    n = (max(0, int(rows)) + int(stripe_rows) - 1) // int(stripe_rows)
+    owner = np.zeros(max(1, n), np.int32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+    if w is not None and len(w) != n_parts:
+        raise ValueError("one weight per part")
+    rc = N.lib().rm_deal_stripes(int(rows), int(stripe_rows), int(n_parts), _ptr(w), _ptr(owner))
+    if rc < 0:
+        raise N.RmError(rc, "rm_deal_stripes")
+    return owner[:rc]
 
 
 def partition_rows(height, n_workers, i):

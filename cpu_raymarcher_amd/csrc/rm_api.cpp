@@ -92,6 +92,15 @@ struct rm_ctx {
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
+    int64_t opt_length = 0;  // vec3.length: 0 Math.hypot (gl-matrix 3.0 - 3.4.3), 1 Math.sqrt(x*x + y*y + z*z)
+    const char *last_kernel = "";
+    // small host tables the sharded entry points need on the device (stripe lists, stripe -> source maps): cached by
+    // content, each in its own allocation, so a table a launch in flight still reads is never overwritten
+    struct DevTable {
+        std::vector<int32_t> host;
+        int32_t *dev = nullptr;
+    };
+    std::vector<DevTable> tables;
     int64_t opt_item_px = 128;  // two 64-pixel batches per queue claim: 7-10 % faster than 64 at the end of round 1, 256 loses
     unsigned int *d_counters = nullptr;  // ring of 1024 x 8 queue heads: a launch owns its slot until 1023 later launches
                                          // have been enqueued (frames in flight on several streams each need their own)
@@ -109,6 +118,11 @@ int fail(rm_ctx *ctx, int code, const std::string &msg) {
 
 int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
     return fail(ctx, RM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// the kernels exist twice: vec3.length = Math.hypot, and = sqrt(x*x + y*y + z*z) (rm_kernels.h, option `length`)
+hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p, hipStream_t stream) {
+    return ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
 }
 
 #define RM_HIP(ctx, call)                                       \
@@ -139,6 +153,27 @@ void free_device_scene(rm_ctx *ctx) {
     (void)hipFree(d.oct_sub_list);
     (void)hipFree(d.bvh_leaves);
     d = DeviceScene();
+}
+
+// device copy of a small host table, cached by content (see rm_ctx::tables)
+int device_table(rm_ctx *ctx, const int32_t *host, size_t n, const int32_t **out) {
+    for (auto &t : ctx->tables)
+        if (t.host.size() == n && std::memcmp(t.host.data(), host, n * sizeof(int32_t)) == 0) {
+            *out = t.dev;
+            return RM_OK;
+        }
+    if (ctx->tables.size() >= 256) {  // far more than any run deals; start over rather than grow without bound
+        RM_HIP(ctx, hipDeviceSynchronize());
+        for (auto &t : ctx->tables) (void)hipFree(t.dev);
+        ctx->tables.clear();
+    }
+    rm_ctx::DevTable t;
+    t.host.assign(host, host + n);
+    RM_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.dev), (n ? n : 1) * sizeof(int32_t)));
+    if (n) RM_HIP(ctx, hipMemcpy(t.dev, host, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = t.dev;
+    ctx->tables.push_back(std::move(t));
+    return RM_OK;
 }
 
 template <typename T>
@@ -207,6 +242,7 @@ int upload_scene(rm_ctx *ctx) {
 int set_scene(rm_ctx *ctx, const float *centers, const double *radii, int n, int accel, bool uploaded, int preset) {
     std::string err;
     rmh::HostScene hs;
+    rmh::set_length_mode(static_cast<int>(ctx->opt_length));
     if (!rmh::build_scene(hs, centers, radii, n, accel, err)) {
         const bool unsupported = err.find("BVH leaf") != std::string::npos;
         return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
@@ -222,6 +258,7 @@ int set_scene(rm_ctx *ctx, const float *centers, const double *radii, int n, int
 int set_scene_general(rm_ctx *ctx, const rmh::PrimDesc *prims, int n, int accel, bool uploaded, int preset) {
     std::string err;
     rmh::HostScene hs;
+    rmh::set_length_mode(static_cast<int>(ctx->opt_length));
     if (!rmh::build_scene_general(hs, prims, n, accel, err)) {
         const bool unsupported = err.find("BVH leaf") != std::string::npos;
         return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
@@ -238,6 +275,7 @@ int set_scene_nodes(rm_ctx *ctx, const rmh::NodeDesc *nodes, int n_nodes, const 
                     bool uploaded, int preset) {
     std::string err;
     rmh::HostScene hs;
+    rmh::set_length_mode(static_cast<int>(ctx->opt_length));
     if (!rmh::build_scene_nodes(hs, nodes, n_nodes, roots, n_roots, accel, err)) {
         const bool unsupported = err.find("BVH leaf") != std::string::npos || err.find("RM_PROG_MAX") != std::string::npos;
         return fail(ctx, unsupported ? RM_E_UNSUPPORTED : RM_E_INVALID, err);
@@ -477,12 +515,14 @@ void rm_destroy(rm_ctx *ctx) {
         (void)hipFree(ctx->d_diag);
         (void)hipFree(ctx->d_counters);
         (void)hipFree(ctx->d_stamps);
+        for (auto &t : ctx->tables) (void)hipFree(t.dev);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
 }
 
 const char *rm_last_error(const rm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *rm_last_kernel(const rm_ctx *ctx) { return ctx && ctx->last_kernel ? ctx->last_kernel : ""; }
 
 int rm_algorithm_from_string(const char *s) {
     if (!s) return RM_ALG_SPHERE_TRACER;
@@ -633,7 +673,7 @@ int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader, void *
     p.iters = static_cast<uint16_t *>(d_iters);
     p.rgba = static_cast<uint8_t *>(d_rgba);
     RM_HIP(ctx, hipSetDevice(ctx->device));
-    RM_HIP(ctx, rm_launch_render(p, static_cast<hipStream_t>(stream)));
+    RM_HIP(ctx, launch_render(ctx, p, static_cast<hipStream_t>(stream)));
     return RM_OK;
 }
 
@@ -670,7 +710,95 @@ int rm_render_stripes_device(rm_ctx *ctx, const rm_job *job, int32_t shader, int
     p.iters = static_cast<uint16_t *>(d_iters);
     p.rgba = static_cast<uint8_t *>(d_rgba);
     RM_HIP(ctx, hipSetDevice(ctx->device));
-    RM_HIP(ctx, rm_launch_render(p, static_cast<hipStream_t>(stream)));
+    RM_HIP(ctx, launch_render(ctx, p, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_deal_stripes(int32_t rows, int32_t stripe_rows, int32_t n_parts, const int32_t *weights, int32_t *owner) {
+    if (rows < 0 || stripe_rows <= 0 || n_parts <= 0 || n_parts > 65535 || !owner) return RM_E_INVALID;
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t w = weights ? weights[p] : 1;
+        if (w <= 0 || w > (1 << 20)) return RM_E_INVALID;
+        total += w;
+    }
+    const int n = static_cast<int>((static_cast<int64_t>(rows) + stripe_rows - 1) / stripe_rows);
+    // smooth weighted round-robin: credit every part its weight, hand the stripe to the richest (lowest index on a
+    // tie), charge it the total.  Equal weights: 0, 1, ..., n_parts - 1, 0, 1, ...
+    std::vector<int64_t> credit(static_cast<size_t>(n_parts), 0);
+    for (int s = 0; s < n; ++s) {
+        int best = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            credit[p] += weights ? weights[p] : 1;
+            if (credit[p] > credit[best]) best = p;
+        }
+        credit[best] -= total;
+        owner[s] = best;
+    }
+    return n;
+}
+
+int rm_render_stripe_list_device(rm_ctx *ctx, const rm_job *job, int32_t shader, int32_t stripe_rows, const int32_t *stripe_ids,
+                                 int32_t n_stripes, void *d_depth, void *d_normal, void *d_sdf, void *d_iters, void *d_rgba,
+                                 void *stream) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context: there is no CPU render path");
+    if (!job) return fail(ctx, RM_E_INVALID, "null job");
+    if (stripe_rows <= 0 || n_stripes < 0 || (n_stripes > 0 && !stripe_ids)) return fail(ctx, RM_E_INVALID, "bad stripe list");
+    const int64_t rows = job->y_end > job->y_start ? static_cast<int64_t>(job->y_end) - job->y_start : 0;
+    const int64_t total = (rows + stripe_rows - 1) / stripe_rows;
+    int64_t mine = 0;
+    for (int k = 0; k < n_stripes; ++k) {
+        if (stripe_ids[k] < 0 || stripe_ids[k] >= total || (k > 0 && stripe_ids[k] <= stripe_ids[k - 1]))
+            return fail(ctx, RM_E_INVALID, "stripe ids must be strictly increasing and inside the row range");
+        const int64_t a = static_cast<int64_t>(stripe_ids[k]) * stripe_rows, b = a + stripe_rows;
+        mine += (b < rows ? b : rows) - a;
+    }
+    RmRenderParams p;
+    int rc = fill_params(ctx, job, p);
+    if (rc) return rc;
+    if (mine == 0) return RM_OK;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = device_table(ctx, stripe_ids, static_cast<size_t>(n_stripes), &p.stripe_ids))) return rc;
+    p.local_rows = static_cast<int32_t>(mine);
+    p.stripe_rows = stripe_rows;
+    p.n_parts = 1;
+    p.part = 0;
+    p.shader = norm_shader(shader);
+    p.depth = static_cast<uint8_t *>(d_depth);
+    p.normal = static_cast<uint8_t *>(d_normal);
+    p.sdf = static_cast<uint16_t *>(d_sdf);
+    p.iters = static_cast<uint16_t *>(d_iters);
+    p.rgba = static_cast<uint8_t *>(d_rgba);
+    RM_HIP(ctx, launch_render(ctx, p, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_assemble_frame_device(rm_ctx *ctx, const void *d_gathered, int64_t rank_stride, int64_t section_offset, int32_t row_bytes,
+                             int32_t height, int32_t stripe_rows, const int32_t *owner, int32_t n_stripes, int32_t world,
+                             void *d_frame, int64_t acc_offset, void *d_acc, void *stream) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (!d_gathered || !d_frame || !owner) return fail(ctx, RM_E_INVALID, "null buffer");
+    if (row_bytes <= 0 || height < 0 || stripe_rows <= 0 || world <= 0 || world > 65535 || rank_stride < 0 || section_offset < 0)
+        return fail(ctx, RM_E_INVALID, "bad frame geometry");
+    if (n_stripes != (height + stripe_rows - 1) / stripe_rows || n_stripes > 65535)
+        return fail(ctx, RM_E_INVALID, "owner[] must name every stripe of the frame (at most 65535)");
+    if (acc_offset >= 0 && (acc_offset % 8 != 0 || rank_stride % 8 != 0)) return fail(ctx, RM_E_INVALID, "accumulators must be 8-byte aligned");
+    // frame stripe s -> (rank, position among that rank's stripes): the rank packed its stripes in increasing y
+    std::vector<int32_t> src(static_cast<size_t>(n_stripes));
+    std::vector<int32_t> seen(static_cast<size_t>(world), 0);
+    for (int s = 0; s < n_stripes; ++s) {
+        if (owner[s] < 0 || owner[s] >= world) return fail(ctx, RM_E_INVALID, "owner out of range");
+        src[s] = (owner[s] << 16) | seen[owner[s]]++;
+    }
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t *d_src = nullptr;
+    int rc = device_table(ctx, src.data(), src.size(), &d_src);
+    if (rc) return rc;
+    RM_HIP(ctx, rm_launch_assemble(static_cast<const unsigned char *>(d_gathered), rank_stride, section_offset, row_bytes, height,
+                                   stripe_rows, d_src, n_stripes, static_cast<unsigned char *>(d_frame), acc_offset, world,
+                                   static_cast<RmDiagDevice *>(d_acc), static_cast<hipStream_t>(stream)));
     return RM_OK;
 }
 
@@ -830,8 +958,9 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     p.oct_prims = ctx->dev.oct_prims;
     p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
     RM_HIP(ctx, hipMemcpyAsync(base, points_xyz, 12 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
-    RM_HIP(ctx, rm_launch_distance(p, reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_dist),
-                                   reinterpret_cast<uint32_t *>(base + o_cnt), ctx->stream));
+    RM_HIP(ctx, (ctx->opt_length ? rm_launch_distance_sqrt : rm_launch_distance)(
+                    p, reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_dist),
+                    reinterpret_cast<uint32_t *>(base + o_cnt), ctx->stream));
     RM_HIP(ctx, hipMemcpyAsync(dist, base + o_dist, 8 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(ctx, hipMemcpyAsync(count, base + o_cnt, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
     RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1024,6 +1153,15 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blocks_per_cu = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "length")) {  // part of the numeric contract, not a measurement knob (rm_raymarch.h)
+        if (value != 0 && value != 1) return fail(ctx, RM_E_INVALID, "length must be 0 (Math.hypot) or 1 (Math.sqrt)");
+        if (ctx->opt_length == value) return RM_OK;
+        ctx->opt_length = value;
+        if (!ctx->have_scene) return RM_OK;
+        // bounding radii of boxes and smooth unions use vec3.length / vec3.distance too: rebuild the active scene
+        ctx->have_scene = false;
+        return ensure_scene(ctx, ctx->scene_is_uploaded ? RM_SCENE_UPLOADED : ctx->scene_preset, ctx->host.accel);
+    }
     return fail(ctx, RM_E_INVALID, std::string("unknown option ") + key);
 }
 
@@ -1049,6 +1187,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;
+    else if (!std::strcmp(key, "length")) *value = ctx->opt_length;
     else return RM_E_INVALID;
     return RM_OK;
 }

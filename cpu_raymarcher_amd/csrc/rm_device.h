@@ -109,6 +109,22 @@ __device__ __forceinline__ double div_in_range(double a, double b) {
     return __builtin_fma(__builtin_fma(-b, q, a), r2, q);
 }
 
+// gl-matrix vec3.length / vec3.distance (sphere.ts:13, box.ts:26, mandelbulb.ts:46).  3.0 - 3.4.3 compute
+// Math.hypot(x, y, z); the pinned 3.4.4 is not available offline and a later patch release may use
+// Math.sqrt(x*x + y*y + z*z), so the formula is ONE switchable function: the kernels are
+// compiled twice, and option `length` = 1 selects the objects built with -DRM_LENGTH_SQRT.  vec3_length is the
+// form with the shared reciprocal (bit-identical to hypot3), vec3_length_plain the one with the compiler's divisions.
+#ifdef RM_LENGTH_SQRT
+__device__ __forceinline__ double vec3_length(float lx, float ly, float lz) {
+    const double x = lx, y = ly, z = lz;
+    return __builtin_sqrt(x * x + y * y + z * z);
+}
+__device__ __forceinline__ double vec3_length_plain(float lx, float ly, float lz) { return vec3_length(lx, ly, lz); }
+#else
+__device__ __forceinline__ double vec3_length(float lx, float ly, float lz) { return hypot3_shared_rcp(lx, ly, lz); }
+__device__ __forceinline__ double vec3_length_plain(float lx, float ly, float lz) { return hypot3(lx, ly, lz); }
+#endif
+
 struct Vec3f {
     float x, y, z;
 };
@@ -124,11 +140,11 @@ struct Ray {
 // rounding is innocuous for +,- when the wide format has >= 2p+2 bits), then
 // Sphere.localSdf (sphere.ts:12-14).
 __device__ __forceinline__ double sphere_sdf(const RmSphere &s, double radius, const Vec3f &p) {
-    return hypot3(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
+    return vec3_length_plain(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
 }
 
 __device__ __forceinline__ double sphere_sdf_fast(const RmSphere &s, double radius, const Vec3f &p) {
-    return hypot3_shared_rcp(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
+    return vec3_length(p.x - s.cx, p.y - s.cy, p.z - s.cz) - radius;
 }
 
 // A binary32 value >= v for the filter's running upper bound: round to nearest, then add more than the
@@ -263,7 +279,7 @@ __device__ __forceinline__ double prim_sdf_general(const RmPrim &q, const Vec3f 
         const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - static_cast<double>(q.half[1]));
         const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - static_cast<double>(q.half[2]));
         const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;  // Math.max(q, 0)
-        const double outside = hypot3_shared_rcp(o0, o1, o2);
+        const double outside = vec3_length(o0, o1, o2);
         const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);  // Math.max(q0, Math.max(q1, q2))
         const double inside = big < 0.f ? static_cast<double>(big) : 0.0;       // Math.min(., 0)
         return outside + inside;
@@ -273,7 +289,7 @@ __device__ __forceinline__ double prim_sdf_general(const RmPrim &q, const Vec3f 
         const double qx = __builtin_sqrt(dx * dx + dz * dz) - q.a;
         return __builtin_sqrt(qx * qx + dy * dy) - q.b;
     }
-    return hypot3_shared_rcp(lx, ly, lz) - q.a;
+    return vec3_length(lx, ly, lz) - q.a;
 }
 
 // BoundingBox.contains (boundingBox.ts:15-21)
@@ -465,11 +481,12 @@ __device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, do
 
 // packed (launch-local) row -> frame row y.  Without striping the tile is the contiguous range
 // [y_start, y_end) of the Job (raymarchWorker.ts:14-15); with striping (multi-GPU sharding) the
-// launch owns every n_parts-th stripe of stripe_rows rows.
+// launch owns every n_parts-th stripe of stripe_rows rows, or the stripes its list names (stripe_ids).
 __device__ __forceinline__ int row_to_y(const RmRenderParams &P, int r) {
     if (P.stripe_rows <= 0) return P.y_start + r;
     const int s = r / P.stripe_rows;
-    return P.y_start + (s * P.n_parts + P.part) * P.stripe_rows + (r - s * P.stripe_rows);
+    const int stripe = P.stripe_ids ? P.stripe_ids[s] : s * P.n_parts + P.part;
+    return P.y_start + stripe * P.stripe_rows + (r - s * P.stripe_rows);
 }
 
 // raymarcher.ts:73,83-88: u, v from full-frame W, H; fromValues, transformMat3, normalize

@@ -13,11 +13,25 @@ struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
     unsigned long long pad;
 };
 
-// Renders rows [y_start, y_end) (runRaymarcher + optional fused shade).
-hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream);
+// rm_kernels.hip and rm_render_v2.hip are compiled twice: as they are (vec3.length = Math.hypot, the gl-matrix 3.0 -
+// 3.4.3 form) and with -DRM_LENGTH_SQRT (vec3.length = Math.sqrt(x*x + y*y + z*z); entry points carry the suffix
+// _sqrt).  Option `length` picks the set (rm_device.h, vec3_length).
+#ifdef RM_LENGTH_SQRT
+#define RM_LEN_VARIANT(name) name##_sqrt
+#define RM_LEN_TAG " [length=sqrt]"
+#else
+#define RM_LEN_VARIANT(name) name
+#define RM_LEN_TAG ""
+#endif
+
+// Renders rows [y_start, y_end) (runRaymarcher + optional fused shade).  *kernel_name (optional) receives the
+// instantiation that was launched (static string).
+hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
+hipError_t rm_launch_render_sqrt(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
 
 // v2 kernel (rm_render_v2.hip); called by rm_launch_render when p.variant == 2
-hipError_t rm_launch_render_v2(const RmRenderParams &p, hipStream_t stream);
+hipError_t rm_launch_render_v2(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
+hipError_t rm_launch_render_v2_sqrt(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
 
 // ShadingModel.shade over n = width * height pixels.
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
@@ -34,6 +48,14 @@ hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t 
 // Scene.getDistance for a batch of points
 hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int64_t n, double *dist,
                               uint32_t *count, hipStream_t stream);
+hipError_t rm_launch_distance_sqrt(const RmRenderParams &p, const float *points, int64_t n, double *dist,
+                                   uint32_t *count, hipStream_t stream);
+
+// Rank 0 of a sharded frame (rm_frame_ops.hip): copies every stripe of a gathered [world x rank_stride] buffer to its
+// place in the row-major frame and combines the ranks' partial diagnostics accumulators.
+hipError_t rm_launch_assemble(const unsigned char *gathered, int64_t rank_stride, int64_t section_offset, int32_t row_bytes,
+                              int32_t height, int32_t stripe_rows, const int32_t *stripe_src, int32_t n_stripes,
+                              unsigned char *frame, int64_t acc_offset, int32_t world, RmDiagDevice *acc, hipStream_t stream);
 
 hipError_t rm_launch_hypot(const float *xyz, int64_t n, double *out, hipStream_t stream);
 // rm_jsmath.h on the device: fn 0 sin, 1 cos, 2 atan2, 3 asin, 4 log, 5 pow, 6 round, 7 atan

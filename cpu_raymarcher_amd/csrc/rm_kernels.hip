@@ -123,7 +123,7 @@ __device__ __forceinline__ void rec_consider(const float4 c, const RmSphereRec *
     const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
     const float err = (len + __builtin_fabsf(c.w) + 1.0f) * 4e-6f;  // sphere_sdf_estimate
     if ((len - c.w) - err <= ub) {
-        const double e = hypot3_shared_rcp(dx, dy, dz) - rec->radius;
+        const double e = vec3_length(dx, dy, dz) - rec->radius;
         if (e < closest) {
             closest = e;
             ub = f32_upper_bound(e);
@@ -178,7 +178,7 @@ __device__ double recs_min(const RmSphereRec *recs, int n, const Vec3f &p, doubl
     for (; k < n; ++k) scan(*reinterpret_cast<const float4 *>(recs + k), k);
     {
         const float4 c = *reinterpret_cast<const float4 *>(recs + k1);
-        const double e = hypot3_shared_rcp(p.x - c.x, p.y - c.y, p.z - c.z) - recs[k1].radius;
+        const double e = vec3_length(p.x - c.x, p.y - c.y, p.z - c.z) - recs[k1].radius;
         closest = e < closest ? e : closest;
     }
     float ub = f32_upper_bound(closest);
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light_d);
 }
 
+#ifndef RM_LENGTH_SQRT  // scene-independent kernels exist once (this file is compiled a second time with -DRM_LENGTH_SQRT)
 // ------------------------------------------------------------------ small kernels
 
 __global__ __launch_bounds__(256) void shade_kernel(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
@@ -618,6 +619,8 @@ __global__ void reduce_init_kernel(RmDiagDevice *acc) {
     acc->pad = 0;
 }
 
+#endif  // !RM_LENGTH_SQRT
+
 template <int ACCEL, int GEN>
 __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
                                                        uint32_t *count) {
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, c
     count[i] = c;
 }
 
+#ifndef RM_LENGTH_SQRT
 __global__ __launch_bounds__(256) void hypot_kernel(const float *xyz, int64_t n, double *out) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (i >= n) return;
@@ -700,8 +704,11 @@ __global__ __launch_bounds__(256) void recip_selftest_kernel(int mode, unsigned 
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+#endif  // !RM_LENGTH_SQRT
+
 }  // namespace
 
+#ifndef RM_LENGTH_SQRT
 hipError_t rm_launch_recip_selftest(int mode, unsigned long long *d_mismatches, hipStream_t stream) {
     hipLaunchKernelGGL(recip_selftest_kernel, dim3(4096), dim3(256), 0, stream, mode, d_mismatches);
     return hipGetLastError();
@@ -713,20 +720,27 @@ hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long lo
     return hipGetLastError();
 }
 
+#endif  // !RM_LENGTH_SQRT
+
 // ---------------------------------------------------------------------- launchers
 
-hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
+hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t stream, const char **kernel_name) {
     const int rows = p.local_rows;
+    if (kernel_name) *kernel_name = "";
     if (rows <= 0 || p.width <= 0) return hipSuccess;
-    if (p.variant == 2 && p.algorithm == 0) return rm_launch_render_v2(p, stream);
+    if (p.variant == 2 && p.algorithm == 0) return RM_LEN_VARIANT(rm_launch_render_v2)(p, stream, kernel_name);
     const int tw = p.tile_w, th = 64 / tw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
     // expression programs keep their position slots and pending values in LDS (rm_program.h)
     const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
-#define RM_V1(A, O, G) hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, shmem, stream, p)
-#define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G); else if (p.accel == 1) RM_V1(1, O, G); else RM_V1(0, O, G); }
+#define RM_V1(A, O, G)                                                                       \
+    {                                                                                        \
+        hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, shmem, stream, p);         \
+        if (kernel_name) *kernel_name = "render_kernel<" #A ", " #O ", " #G ">" RM_LEN_TAG;  \
+    }
+#define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G) else if (p.accel == 1) RM_V1(1, O, G) else RM_V1(0, O, G) }
     if (p.general == 3) {
         if (p.algorithm == 0) RM_V1A(false, 3) else RM_V1A(true, 3)
     } else if (p.general == 2) {
@@ -741,6 +755,7 @@ hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifndef RM_LENGTH_SQRT
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal, const uint16_t *sdf,
                            const uint16_t *iters, uint8_t *rgba, const float light[3], hipStream_t stream) {
     if (n <= 0) return hipSuccess;
@@ -766,7 +781,9 @@ hipError_t rm_launch_reduce(const uint16_t *sdf, const uint16_t *iters, int64_t 
     return hipGetLastError();
 }
 
-hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int64_t n, double *dist, uint32_t *count,
+#endif  // !RM_LENGTH_SQRT
+
+hipError_t RM_LEN_VARIANT(rm_launch_distance)(const RmRenderParams &p, const float *points, int64_t n, double *dist, uint32_t *count,
                               hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
@@ -780,6 +797,7 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
     return hipGetLastError();
 }
 
+#ifndef RM_LENGTH_SQRT
 __global__ __launch_bounds__(256) void jsmath_kernel(int fn, const double *a, const double *b, int64_t n, double *out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= n) return;
@@ -808,3 +826,4 @@ hipError_t rm_launch_hypot(const float *xyz, int64_t n, double *out, hipStream_t
     hipLaunchKernelGGL(hypot_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, xyz, n, out);
     return hipGetLastError();
 }
+#endif  // !RM_LENGTH_SQRT

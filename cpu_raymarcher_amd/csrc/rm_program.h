@@ -66,7 +66,7 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
     float z0 = p0, z1 = p1, z2 = p2;
     double dr = 1.0, r = 0.0;
     for (int i = 0; i < iterations; ++i) {
-        r = hypot3_shared_rcp(z0, z1, z2);
+        r = vec3_length(z0, z1, z2);
         if (r > 2.0) break;
         double theta = mb_atan2(z1, z0);
         double phi = mb_asin(static_cast<double>(z2) / r);
@@ -133,7 +133,7 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
                 const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - I.p[2]);
                 const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
                 const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
-                d = hypot3_shared_rcp(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
+                d = vec3_length(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
             } else if (op == 2) {  // torus.ts:14-25
                 const double dx = lx, dy = ly, dz = lz;
                 const double qx = __builtin_sqrt(dx * dx + dz * dz) - I.p[0];
@@ -141,7 +141,7 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
             } else if (MB && op == 3) {
                 d = mandelbulb_sdf(I.p, lx, ly, lz, time);
             } else {  // sphere.ts:12-14
-                d = hypot3_shared_rcp(lx, ly, lz) - I.p[0];
+                d = vec3_length(lx, ly, lz) - I.p[0];
             }
             val[sp * nt] = d;
             sp += 1;

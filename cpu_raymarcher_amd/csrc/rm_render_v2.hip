@@ -1137,9 +1137,10 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
 
 }  // namespace
 
-hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
+hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipStream_t stream, const char **kernel_name) {
     RmRenderParams p = p_in;
     const int rows = p.local_rows;
+    if (kernel_name) *kernel_name = "";
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (!p.tile_counters) return hipErrorInvalidValue;
     if (p.item_px != 64 && p.item_px != 128 && p.item_px != 256) p.item_px = 64;
@@ -1206,16 +1207,22 @@ hipError_t rm_launch_render_v2(const RmRenderParams &p_in, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(blocks), block(256);
-#define RM_V2(A, L) hipLaunchKernelGGL((render_kernel_v2<A, L>), grid, block, shmem, stream, p)
-    if (p.accel == 2) {
-        if (lds && rel && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true, true>), grid, block, shmem, stream, p);
-        else if (lds && rel) hipLaunchKernelGGL((render_kernel_v2<2, true, false, true>), grid, block, shmem, stream, p);
-        else if (lds && p.uniform_radius) hipLaunchKernelGGL((render_kernel_v2<2, true, true>), grid, block, shmem, stream, p);
-        else if (lds) RM_V2(2, true);
-        else RM_V2(2, false);
+#define RM_V2X(A, L, U, R)                                                                                  \
+    {                                                                                                       \
+        hipLaunchKernelGGL((render_kernel_v2<A, L, U, R>), grid, block, shmem, stream, p);                  \
+        if (kernel_name) *kernel_name = "render_kernel_v2<" #A ", " #L ", " #U ", " #R ">" RM_LEN_TAG;      \
     }
-    else if (p.accel == 1) { if (lds) RM_V2(1, true); else RM_V2(1, false); }
-    else { if (lds) RM_V2(0, true); else RM_V2(0, false); }
+#define RM_V2(A, L) RM_V2X(A, L, false, false)
+    if (p.accel == 2) {
+        if (lds && rel && p.uniform_radius) RM_V2X(2, true, true, true)
+        else if (lds && rel) RM_V2X(2, true, false, true)
+        else if (lds && p.uniform_radius) RM_V2X(2, true, true, false)
+        else if (lds) RM_V2(2, true)
+        else RM_V2(2, false)
+    }
+    else if (p.accel == 1) { if (lds) RM_V2(1, true) else RM_V2(1, false) }
+    else { if (lds) RM_V2(0, true) else RM_V2(0, false) }
+#undef RM_V2X
 #undef RM_V2
     return hipGetLastError();
 }

@@ -369,6 +369,15 @@ struct OctBuilder {
 
 }  // namespace
 
+// gl-matrix vec3.length / vec3.distance as the scene builder uses them (box.ts:33, smoothUnion.ts:45): Math.hypot in
+// 3.0 - 3.4.3, or Math.sqrt(x*x + y*y + z*z) when the ctx's option `length` is 1 (set per build by the API layer).
+namespace { thread_local int g_length_sqrt = 0; }
+void set_length_mode(int use_sqrt) { g_length_sqrt = use_sqrt ? 1 : 0; }
+double vec3_length_host(double x, double y, double z) {
+    if (g_length_sqrt) return std::sqrt(x * x + y * y + z * z);
+    return js_hypot3(x, y, z);
+}
+
 double js_hypot3(double x, double y, double z) {
     double v[3] = {std::fabs(x), std::fabs(y), std::fabs(z)};
     double big = 0.0;
@@ -752,7 +761,7 @@ bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, 
         double local_radius;
         if (d.type == 1) {  // box.ts:8-11,32-34
             for (int k = 0; k < 3; ++k) q.half[k] = to_f32(d.params[k]);
-            local_radius = js_hypot3(q.half[0], q.half[1], q.half[2]);
+            local_radius = vec3_length_host(q.half[0], q.half[1], q.half[2]);
         } else if (d.type == 2) {  // torus.ts:27-29
             q.a = d.params[0];
             q.b = d.params[1];
@@ -825,7 +834,7 @@ struct Forest {
         const NodeDesc &d = nodes[i];
         switch (d.type) {
             case 0: return d.params[0];
-            case 1: return js_hypot3(to_f32(d.params[0]), to_f32(d.params[1]), to_f32(d.params[2]));
+            case 1: return vec3_length_host(to_f32(d.params[0]), to_f32(d.params[1]), to_f32(d.params[2]));
             case 2: return d.params[0] + d.params[1];
             case 3: return 2.5;                                   // mandelbulb.ts:80-83
             case 10: return local_radius(d.a) + d.params[0];      // round.ts:27-30
@@ -837,8 +846,8 @@ struct Forest {
                 float p1[3], p2[3];
                 world_pos(d.a, p1);
                 world_pos(d.b, p2);
-                const double dist = js_hypot3(double(p2[0]) - double(p1[0]), double(p2[1]) - double(p1[1]),
-                                              double(p2[2]) - double(p1[2]));
+                const double dist = vec3_length_host(double(p2[0]) - double(p1[0]), double(p2[1]) - double(p1[1]),
+                                                     double(p2[2]) - double(p1[2]));
                 return js_max2(local_radius(d.a), local_radius(d.b)) + dist * 0.5;
             }
         }

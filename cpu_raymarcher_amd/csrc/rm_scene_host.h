@@ -77,6 +77,10 @@ struct HostScene {
 
 // V8 Math.hypot for three arguments (used by boundingBox.ts:46,142-144)
 double js_hypot3(double x, double y, double z);
+// vec3.length / vec3.distance of the scene builder (box.ts:33, smoothUnion.ts:45): Math.hypot, or sqrt(x*x+y*y+z*z)
+// after set_length_mode(1) (thread-local; the API layer sets it from the ctx before every build)
+void set_length_mode(int use_sqrt);
+double vec3_length_host(double x, double y, double z);
 
 // sceneManager.ts:102-170: sphere-only presets 0..4; false for the others
 bool preset_spheres(int index, std::vector<float> &centers, std::vector<double> &radii);

@@ -121,6 +121,9 @@ typedef struct rm_diagnostics {
 RM_API int rm_create(int device, rm_ctx **out);
 RM_API void rm_destroy(rm_ctx *ctx);
 RM_API const char *rm_last_error(const rm_ctx *ctx); /* never NULL */
+/* the render-kernel instantiation the most recent render entry launched ("" before the first; never NULL):
+ * measurement aid, so that a benchmark line names the kernel that really ran */
+RM_API const char *rm_last_kernel(const rm_ctx *ctx);
 RM_API const char *rm_version(void);
 
 /* string -> enum with the reference's defaulting rules (never fail) */
@@ -237,6 +240,34 @@ RM_API int rm_render_stripes_device(rm_ctx *ctx, const rm_job *job, int32_t shad
 /* number of rows part `part` owns (>= 0), or RM_E_INVALID */
 RM_API int rm_stripe_rows(int32_t y_start, int32_t y_end, int32_t stripe_rows, int32_t n_parts, int32_t part);
 
+/* Weighted deal of the stripes of `rows` rows over n_parts parts (replaces the equal ceil(H/N) shares of
+ * main.ts:444-449 when the parts are NOT equally loaded: the root of the gather also reassembles the frame, so it
+ * gets a smaller share).  owner[s] receives the part of stripe s (s < ceil(rows / stripe_rows) = the return value);
+ * weights[p] > 0 are relative shares (NULL: equal).  Smooth weighted round-robin: every part's stripes stay spread
+ * over the whole frame (load balance: the top and bottom of a frame are mostly root-box misses), and equal weights
+ * give exactly the round-robin deal of rm_render_stripes_device.  Deterministic integer arithmetic: every rank
+ * computes the same deal from the same weights.  Host-side, no ctx. */
+RM_API int rm_deal_stripes(int32_t rows, int32_t stripe_rows, int32_t n_parts, const int32_t *weights, int32_t *owner);
+
+/* One launch for an explicit list of stripes: stripe_ids[0 .. n_stripes) (strictly increasing, host memory, copied),
+ * stripe k of the list being rows [y_start + id * stripe_rows, ...) of the Job, packed in list order.  Buffers must
+ * hold the rows the list covers (the frame's last stripe may be partial). */
+RM_API int rm_render_stripe_list_device(rm_ctx *ctx, const rm_job *job, int32_t shader, int32_t stripe_rows,
+                                        const int32_t *stripe_ids, int32_t n_stripes, void *d_depth, void *d_normal,
+                                        void *d_sdf, void *d_iters, void *d_rgba, void *stream);
+
+/* Rank 0's fan-in (replaces `buffer.set(tile, yStart * width)` per worker result, main.ts:461-468, and the combined
+ * diagnostics of main.ts:528-548) as ONE kernel: d_gathered holds `world` per-rank packed buffers rank_stride bytes
+ * apart (what a gather delivers); the section at section_offset of each holds that rank's stripes, packed in
+ * increasing y, rows of row_bytes = width * bytes-per-pixel.  owner[s] (host, n_stripes = ceil(height / stripe_rows)
+ * entries, as rm_deal_stripes returns them) names the rank of frame stripe s.  Writes the row-major frame to d_frame.
+ * acc_offset >= 0: each rank's 32-byte partial diagnostics accumulator (rm_reduce_counters_enqueue layout) sits at
+ * that offset of its packed buffer; their combination is written to d_acc (acc_offset < 0 or d_acc NULL: skipped). */
+RM_API int rm_assemble_frame_device(rm_ctx *ctx, const void *d_gathered, int64_t rank_stride, int64_t section_offset,
+                                    int32_t row_bytes, int32_t height, int32_t stripe_rows, const int32_t *owner,
+                                    int32_t n_stripes, int32_t world, void *d_frame, int64_t acc_offset, void *d_acc,
+                                    void *stream);
+
 /* Replaces ShadingModel.shade(shaded, depth, normal, sdfEval, iters, width, height)
  * (shadingModel.ts:8-17 and the four models), host buffers. */
 RM_API int rm_shade(rm_ctx *ctx, int32_t shader, int32_t width, int32_t height,
@@ -304,7 +335,12 @@ RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
  *   uniform 0|1   scenes whose spheres share one radius: rank leaf candidates by squared centre distance (v2, default 1)
  *   rel 0|1       BVH node boxes relative to the frame's ray origin, as doubles in LDS, when they fit (v2, default 1)
  *   cull 0|1      whole 64-pixel batches find their hit BVH leaves by a bundle-frustum cull (v2, <= 256 leaves, default 1)
- *   lds_kb 16..64 LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (32: five workgroups per CU; 40: four) */
+ *   lds_kb 16..64 LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (32: five workgroups per CU; 40: four)
+ * The one option that is NOT a measurement knob but part of the numeric contract:
+ *   length 0|1    gl-matrix vec3.length / vec3.distance (sphere.ts:12-14, box.ts:26,33, mandelbulb.ts:46, smoothUnion.ts:45):
+ *                 0 = Math.hypot(x, y, z) (gl-matrix 3.0 - 3.4.3, default), 1 = Math.sqrt(x*x + y*y + z*z) (the form a later
+ *                 3.4.x release may use).  Results differ by <= 1 ulp(f64) per distance; the active scene is
+ *                 rebuilt (bounding radii of boxes and smooth unions use it too). */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
 

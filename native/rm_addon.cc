@@ -3,9 +3,13 @@
 // describes: the worker keeps `Job` / `Result` (src/workers/raymarchWorker.ts:10-31) and
 // replaces the body of onmessage (raymarchWorker.ts:33-92) with renderTile(job, buffers).
 //
-// One rm_ctx per addon instance (= per worker thread; the ABI is not thread-safe per ctx).
+// One rm_ctx per addon INSTANCE, i.e. per napi_env: node loads the addon once per worker_threads
+// worker (the .so itself is mapped once per process), so each worker of the reference's pool
+// (main.ts:318-321) owns its own context.  The ABI is not thread-safe per ctx; nothing here is
+// process-global.  The ctx lives in the env's instance data and is destroyed when the env goes.
 // Nothing here throws: every call returns the rm_status code (0 ok, -2 = RM_E_UNSUPPORTED ->
 // the caller keeps its CPU path for that job), lastError() has the text.
+#define NAPI_VERSION 6  // napi_set_instance_data (node >= 12.17)
 #include <node_api.h>
 
 #include <cmath>
@@ -17,7 +21,21 @@
 
 namespace {
 
-rm_ctx *g_ctx = nullptr;
+struct Addon {
+    rm_ctx *ctx = nullptr;
+};
+
+void addon_finalize(napi_env, void *data, void *) {
+    Addon *a = static_cast<Addon *>(data);
+    if (a->ctx) rm_destroy(a->ctx);
+    delete a;
+}
+
+Addon *addon_of(napi_env env) {
+    void *data = nullptr;
+    if (napi_get_instance_data(env, &data) != napi_ok) return nullptr;
+    return static_cast<Addon *>(data);
+}
 
 double num_prop(napi_env env, napi_value obj, const char *name, double dflt) {
     napi_value v;
@@ -101,11 +119,13 @@ napi_value Create(napi_env env, napi_callback_info info) {
     napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
     int32_t dev = 0;
     if (argc >= 1) napi_get_value_int32(env, a[0], &dev);
-    if (g_ctx) {
-        rm_destroy(g_ctx);
-        g_ctx = nullptr;
+    Addon *ad = addon_of(env);
+    if (!ad) return make_int(env, RM_E_INVALID);
+    if (ad->ctx) {  // this env's own context only: another worker's context is never touched
+        rm_destroy(ad->ctx);
+        ad->ctx = nullptr;
     }
-    return make_int(env, rm_create(dev, &g_ctx));
+    return make_int(env, rm_create(dev, &ad->ctx));
 }
 
 // renderTile(job, depth: Uint8ClampedArray, normal: Uint8ClampedArray, sdfEval: Uint16Array, iters: Uint16Array)
@@ -113,6 +133,8 @@ napi_value RenderTile(napi_env env, napi_callback_info info) {
     size_t argc = 5;
     napi_value a[5];
     napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Addon *ad = addon_of(env);
+    rm_ctx *g_ctx = ad ? ad->ctx : nullptr;
     if (!g_ctx || argc < 5) return make_int(env, RM_E_INVALID);
     const rm_job job = job_from_js(env, a[0]);
     const size_t rows = job.y_end > job.y_start ? static_cast<size_t>(job.y_end - job.y_start) : 0;
@@ -131,6 +153,8 @@ napi_value Shade(napi_env env, napi_callback_info info) {
     size_t argc = 8;
     napi_value a[8];
     napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Addon *ad = addon_of(env);
+    rm_ctx *g_ctx = ad ? ad->ctx : nullptr;
     if (!g_ctx || argc < 8) return make_int(env, RM_E_INVALID);
     char name[64];
     size_t n = 0;
@@ -153,6 +177,8 @@ napi_value Diagnostics(napi_env env, napi_callback_info info) {
     size_t argc = 2;
     napi_value a[2];
     napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Addon *ad = addon_of(env);
+    rm_ctx *g_ctx = ad ? ad->ctx : nullptr;
     if (!g_ctx || argc < 2) return make_int(env, RM_E_INVALID);
     size_t b0, b1;
     uint16_t *sdf = static_cast<uint16_t *>(typed(env, a[0], &b0));
@@ -178,7 +204,8 @@ napi_value Diagnostics(napi_env env, napi_callback_info info) {
 
 napi_value LastError(napi_env env, napi_callback_info) {
     napi_value out;
-    const char *s = rm_last_error(g_ctx);
+    Addon *ad = addon_of(env);
+    const char *s = rm_last_error(ad ? ad->ctx : nullptr);
     napi_create_string_utf8(env, s, std::strlen(s), &out);
     return out;
 }
@@ -191,6 +218,7 @@ napi_value Version(napi_env env, napi_callback_info) {
 }
 
 napi_value Init(napi_env env, napi_value exports) {
+    napi_set_instance_data(env, new Addon(), addon_finalize, nullptr);
     const napi_property_descriptor props[] = {
         {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"renderTile", nullptr, RenderTile, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -893,9 +893,94 @@ function cmdJsMath(fn, aPath, bPath, outPath) {
   fs.writeFileSync(outPath, Buffer.from(out.buffer));
 }
 
+// The reference's frame loop on its own terms (main.ts:318, 434-548 minus the DOM): a pool of
+// N = max(1, min(4, cores - 1)) workers (main.ts:318), per frame one Job per worker over contiguous ceil(H/N)-row
+// tiles (main.ts:444-449), tile buffers transferred back and set into the frame buffers (main.ts:461-468), then
+// ShadingModel.shade (main.ts:493-501) and the diagnostics pass (main.ts:528-548) on the main thread.  `frames`
+// whole frames are timed after one warm-up frame.  cfg.rowStride = k > 1 renders every k-th row of every tile
+// (a bounded sample spread over the whole frame; the caller scales the time by k and says so).  Like the
+// reference's worker (raymarchWorker.ts:37-38) every job builds its scene anew (once here, twice there).
+function poolWorker() {
+  const { parentPort } = require('worker_threads');
+  parentPort.on('message', (job) => {
+    const S = makeScene(presetSpheres(job.scenePresetIndex), job.accelerationStructure, false);
+    const cam = cameraMatrix(job.camera.pitch, job.camera.yaw);
+    const k = job.rowStride || 1;
+    const rowsList = [];
+    for (let y = job.yStart; y < job.yEnd; y += k) rowsList.push(y);
+    const W = job.width, n = rowsList.length;
+    const depth = new Uint8ClampedArray(W * n), normal = new Uint8ClampedArray(W * n * 3);
+    const sdf = new Uint16Array(W * n), iters = new Uint16Array(W * n);
+    gTime = job.time || 0;
+    if (k === 1) {
+      const r = renderTile(S, cam, W, job.height, job.yStart, job.yEnd, job.algorithm);
+      depth.set(r.depth); normal.set(r.normal); sdf.set(r.sdf); iters.set(r.iters);
+    } else {
+      rowsList.forEach((y, j) => {
+        const r = renderTile(S, cam, W, job.height, y, y + 1, job.algorithm);
+        depth.set(r.depth, j * W); normal.set(r.normal, j * W * 3); sdf.set(r.sdf, j * W); iters.set(r.iters, j * W);
+      });
+    }
+    parentPort.postMessage({ yStart: job.yStart, yEnd: job.yEnd, rows: n, depth, normal, sdfEval: sdf, iters },
+      [depth.buffer, normal.buffer, sdf.buffer, iters.buffer]);
+  });
+}
+
+function cmdPool(cfgPath) {
+  const { Worker } = require('worker_threads');
+  const os = require('os');
+  const cfg = JSON.parse(fs.readFileSync(cfgPath, 'utf8'));
+  const cores = cfg.cores || os.cpus().length;
+  const N = cfg.workers || Math.max(1, Math.min(4, cores - 1)); // main.ts:318
+  const W = cfg.width, H = cfg.height, k = cfg.rowStride || 1, frames = cfg.frames || 5;
+  const workers = [];
+  for (let i = 0; i < N; i++) workers.push(new Worker(__filename, { argv: ['pool-worker'] }));
+  const rowsPerWorker = Math.ceil(H / N); // main.ts:444
+  const tiles = [];
+  let sampled = 0;
+  for (let i = 0; i < N; i++) {
+    const y0 = Math.min(i * rowsPerWorker, H), y1 = Math.min((i + 1) * rowsPerWorker, H); // main.ts:448-449
+    tiles.push([y0, y1, sampled]);
+    sampled += Math.ceil(Math.max(0, y1 - y0) / k);
+  }
+  const depthB = new Uint8ClampedArray(W * sampled), normalB = new Uint8ClampedArray(W * sampled * 3);
+  const sdfB = new Uint16Array(W * sampled), itersB = new Uint16Array(W * sampled), out = new Uint8ClampedArray(W * sampled * 4);
+  let diag = null;
+  const frame = (f) => Promise.all(workers.map((w, i) => new Promise((resolve) => {
+    w.once('message', (r) => {
+      const off = tiles[i][2] * W; // r.yStart * width in the reference; sampled rows are packed here
+      depthB.set(r.depth, off); normalB.set(r.normal, off * 3); sdfB.set(r.sdfEval, off); itersB.set(r.iters, off);
+      resolve();
+    });
+    w.postMessage({ width: W, height: H, time: 0, yStart: tiles[i][0], yEnd: tiles[i][1], rowStride: k,
+      camera: { pitch: cfg.pitch || 0, yaw: cfg.yaw || 0 }, algorithm: cfg.algorithm || 'sphere-tracer',
+      scenePresetIndex: cfg.preset, accelerationStructure: cfg.accel });
+  }))).then(() => {
+    const rgba = shade(cfg.shader || 'normal', depthB, normalB, sdfB, itersB, W, sampled); // main.ts:493-501
+    out.set(rgba);
+    let sumS = 0, sumI = 0, mx = 0, mn = Number.MAX_SAFE_INTEGER; // main.ts:528-548
+    for (let i = 0; i < sdfB.length; i++) { const c = sdfB[i]; sumS += c; sumI += itersB[i]; if (c > mx) mx = c; if (c < mn) mn = c; }
+    diag = { sum_sdf: sumS, sum_iters: sumI, max_sdf: mx, min_sdf: mn };
+  });
+  (async () => {
+    await frame(-1); // warm-up (JIT, scene build code paths)
+    const times = [];
+    for (let f = 0; f < frames; f++) {
+      const t0 = process.hrtime.bigint();
+      await frame(f);
+      times.push(Number(process.hrtime.bigint() - t0) / 1e6);
+    }
+    await Promise.all(workers.map((w) => w.terminate()));
+    process.stdout.write(JSON.stringify({ workers: N, cores, frames, row_stride: k, sampled_rows: sampled, frame_ms: times,
+      diagnostics: diag, engine: 'node ' + process.version + ' v8 ' + process.versions.v8 }) + '\n');
+  })();
+}
+
 const [cmd, a1, a2, a3, a4] = process.argv.slice(2);
-if (cmd === 'render') cmdRender(a1, a2);
+if (cmd === 'pool-worker') poolWorker();
+else if (cmd === 'pool') cmdPool(a1);
+else if (cmd === 'render') cmdRender(a1, a2);
 else if (cmd === 'jsmath') cmdJsMath(a1, a2, a3, a4);
 else if (cmd === 'hypot') cmdHypot(a1, a2);
 else if (cmd === 'camera') cmdCamera(a1, a2);
-else { process.stderr.write('usage: node rm_oracle.js render|hypot|camera|jsmath ...\n'); process.exit(2); }
+else { process.stderr.write('usage: node rm_oracle.js render|pool|hypot|camera|jsmath ...\n'); process.exit(2); }

@@ -32,7 +32,7 @@ def main():
     shr = D.ShardedFrameRenderer(layout, 0, 1, None, u8, dist, render_all=render_all, frames_in_flight=S,
                                  streams=streams)
     shr.world = 2  # take the gather branch although there is one rank: rank 0 gathers from itself
-    asm = D.GpuFrameAssembler(layout, dev, S)
+    asm = D.GpuFrameAssembler(layout, dev, S, ctx=ctx)
     shr.recv = asm.gather_lists()
     slots = [shr.submit() for _ in range(S)]
     for s in slots:
@@ -43,6 +43,9 @@ def main():
     torch.cuda.synchronize()
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tl = [torch.zeros(2, dtype=torch.float64, device=dev)]  # the calibration exchange of bench.py --root-share auto
+    dist.all_gather(tl, torch.tensor([0.25, 0.5], dtype=torch.float64, device=dev))
+    assert tl[0].tolist() == [0.25, 0.5]
     ok = True
     for s in slots:
         ok &= bool(torch.equal(asm.recv2d[s][0], shr.send[s]))

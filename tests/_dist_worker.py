@@ -20,7 +20,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     W, H = 96, 70  # H not a multiple of stripe * world
     sections = ("rgba", "sdf", "iters", "depth", "normal")
-    layout = D.FrameLayout(W, H, world, sections, mode, stripe)
+    weights = [int(w) for w in sys.argv[5].split(",")] if len(sys.argv) > 5 and sys.argv[5] else None
+    layout = D.FrameLayout(W, H, world, sections, mode, stripe, weights=weights)
     sc = O.OracleScene(preset=3, accel="BVH")
     sc.set_angles(0.2, 0.4)
 

@@ -17,9 +17,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,mode,stripe,in_flight", [(2, "interleaved", 16, 2), (2, "contiguous", 16, 2),
-                                                         (3, "interleaved", 4, 2), (2, "interleaved", 8, 4)])
-def test_shard_gather_reassemble(tmp_path, world, mode, stripe, in_flight):
+@pytest.mark.parametrize("world,mode,stripe,in_flight,weights", [
+    (2, "interleaved", 16, 2, ""), (2, "contiguous", 16, 2, ""), (3, "interleaved", 4, 2, ""), (2, "interleaved", 8, 4, ""),
+    (3, "interleaved", 4, 2, "400,1000,1000"),  # weighted deal: the gather's root renders a smaller share
+    (2, "interleaved", 8, 3, "1,3")])
+def test_shard_gather_reassemble(tmp_path, world, mode, stripe, in_flight, weights):
     out = tmp_path / "result.txt"
     port = _free_port()
     procs = []
@@ -27,7 +29,7 @@ def test_shard_gather_reassemble(tmp_path, world, mode, stripe, in_flight):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), mode, str(stripe),
-                                       str(out), str(in_flight)], env=env))
+                                       str(out), str(in_flight), weights], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
     assert out.read_text() == "OK"
@@ -64,3 +66,30 @@ def test_layout_tail_travels_after_the_sections(rm):
     parts = [sdf[r::8] for r in range(8)]
     assert sum(int(p.sum()) for p in parts) == int(sdf.sum())
     assert max(int(p.max()) for p in parts) == int(sdf.max()) and min(int(p.min()) for p in parts) == int(sdf.min())
+
+
+def test_weighted_stripe_deal(rm):
+    """rm_deal_stripes: equal weights give the round-robin deal of rm_render_stripes_device; any weights deal every
+    stripe exactly once, in proportion, and spread every rank's stripes over the whole frame (no rank's stripes bunch
+    at the light top / bottom of the frame)."""
+    import numpy as np
+    from cpu_raymarcher_amd import distributed as D
+    from cpu_raymarcher_amd.context import deal_stripes
+    for rows, stripe, n in ((2160, 16, 8), (2160, 7, 8), (131, 16, 3), (1, 16, 4), (0, 16, 2)):
+        own = deal_stripes(rows, stripe, n)
+        assert list(own) == [s % n for s in range(-(-rows // stripe))]
+        assert D.owned_rows(rows, n, 1, "interleaved", stripe) == D.owned_rows(rows, n, 1, "interleaved", stripe, [5] * n)
+    w = [550, 1000, 1000, 1000, 1000, 1000, 1000, 1000]
+    own = deal_stripes(2160, 16, 8, w)
+    cnt = np.bincount(own, minlength=8)
+    assert cnt.sum() == 135 and all(abs(c - 135 * wi / sum(w)) < 1.0 for c, wi in zip(cnt, w))
+    for r in range(8):  # gaps between consecutive stripes of a rank stay near total / weight
+        ids = np.nonzero(own == r)[0]
+        assert np.diff(ids).max() <= np.ceil(sum(w) / w[r]) + 1
+    assert D.balanced_weights(8, 0.0, 0.2e-3) == [1000] * 8
+    bw = D.balanced_weights(8, 0.05e-3, 0.2e-3)  # 50 us of root overhead against a 200 us shard
+    assert bw[1:] == [1000] * 7 and 700 < bw[0] < 800
+    assert D.balanced_weights(8, 1.0, 0.2e-3)[0] >= 200  # rank 0 keeps at least a quarter share
+    lay = D.FrameLayout(3840, 2160, 8, ("rgba",), "interleaved", 16, tail=32, weights=bw)
+    assert sorted(sum((lay.rows(r) for r in range(8)), [])) == [(a, min(a + 16, 2160)) for a in range(0, 2160, 16)]
+    assert lay.cap == max(sum(b - a for a, b in lay.rows(r)) for r in range(8))

@@ -81,3 +81,38 @@ def test_node_worker_reports_errors(addon, tmp_path):
     p = subprocess.run([NODE, os.path.join(ROOT, "native", "render_cli.js"), str(tmp_path / "cfg.json"),
                         str(tmp_path / "out")], stdout=subprocess.PIPE)
     assert p.returncode == 1 and json.loads(p.stdout)["code"] == -1  # RM_E_INVALID surfaces as an Error with .code
+
+
+def test_worker_pool_owns_one_context_per_worker(addon, tmp_path):
+    """the addon kept one process-global ctx, so a worker's create() destroyed the ctx another
+    worker was using.  Now the ctx is per napi_env.  Four worker_threads on host-only contexts, every second job
+    re-creating the worker's own ctx while the others are in renderTile: every status must be RM_E_NO_DEVICE
+    (a destroyed foreign ctx would crash or report RM_E_INVALID)."""
+    cfg = dict(width=64, height=48, workers=4, frames=8, device=-1, preset=3, accel="BVH", recreate=True)
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "native", "pool_cli.js"), str(tmp_path / "cfg.json")], timeout=120)
+    res = json.loads(out)
+    assert res["statuses"] == [-3] * (4 * 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(preset=3, accel="BVH", width=320, height=203, workers=4, frames=3, pitch=0.1, yaw=0.3),
+    dict(preset=3, accel="Octree", width=200, height=120, workers=3, frames=2, recreate=True),
+])
+def test_worker_pool_renders_concurrently(addon, oracle, tmp_path, cfg):
+    """The reference's pool (main.ts:318-321, fan-out/fan-in :444-468) over worker_threads: N workers render their
+    ceil(H/N)-row tiles at the same time, each through its own rm_ctx on the same GPU; the gathered frame of the
+    last frame (yaw advanced by 0.015 per frame, main.ts:438-441) equals the oracle's."""
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "native", "pool_cli.js"), str(tmp_path / "cfg.json"),
+                                   str(tmp_path / "out")], timeout=300)
+    res = json.loads(out)
+    assert res["statuses"] == [0] * (cfg["workers"] * cfg["frames"])
+    W, H = cfg["width"], cfg["height"]
+    sc = oracle.OracleScene(preset=cfg["preset"], accel=cfg["accel"])
+    sc.set_angles(cfg.get("pitch", 0.0), cfg.get("yaw", 0.0) + 0.015 * (cfg["frames"] - 1))
+    d, n, s, i = sc.render(W, H)
+    for name, arr in (("depth", d), ("normal", n), ("sdf", s), ("iters", i)):
+        got = np.fromfile(str(tmp_path / "out" / (name + ".bin")), dtype=arr.dtype)
+        assert np.array_equal(got, arr), name

@@ -42,7 +42,7 @@ def _check_buffers(npx, bufs, need_device=None):
             raise ValueError("%s must be a numpy array or a torch tensor, not %s" % (name, type(b).__name__))
         if not contiguous:
             raise ValueError("%s buffer must be C-contiguous" % name)
-        if itemsize != esz:
+        if itemsize != esz and not (dev and itemsize == 1):  # device side: byte views into a packed gather buffer are fine
             raise ValueError("%s buffer must have %d-byte elements (got %d)" % (name, esz, itemsize))
         if nbytes < npx * _BPP[name]:
             raise ValueError("%s buffer holds %d bytes, the tile needs %d" % (name, nbytes, npx * _BPP[name]))

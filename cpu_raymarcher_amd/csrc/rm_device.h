@@ -485,7 +485,16 @@ __device__ __forceinline__ double oct_skip(const RmOctNode &nd, const Ray &r, do
 __device__ __forceinline__ int row_to_y(const RmRenderParams &P, int r) {
     if (P.stripe_rows <= 0) return P.y_start + r;
     const int s = r / P.stripe_rows;
-    const int stripe = P.stripe_ids ? P.stripe_ids[s] : s * P.n_parts + P.part;
+    int stripe;
+    if (P.stripe_ids) {
+        // rows past the launch's last row are asked for too (the bundle of a batch that hangs over the end of the tile
+        // rows): never read past the list, and keep the mapping increasing there like the round-robin rule does
+        const int last = (P.local_rows - 1) / P.stripe_rows;
+        const int k = s < last ? s : last;
+        stripe = P.stripe_ids[k] + (s - k);
+    } else {
+        stripe = s * P.n_parts + P.part;
+    }
     return P.y_start + stripe * P.stripe_rows + (r - s * P.stripe_rows);
 }
 

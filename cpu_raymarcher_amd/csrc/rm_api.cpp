@@ -92,6 +92,7 @@ struct rm_ctx {
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
+    int64_t opt_n0_batch = 64;  // v2 BVH: see RmRenderParams::n0_batch
     int64_t opt_length = 0;  // vec3.length: 0 Math.hypot (gl-matrix 3.0 - 3.4.3), 1 Math.sqrt(x*x + y*y + z*z)
     const char *last_kernel = "";
     // small host tables the sharded entry points need on the device (stripe lists, stripe -> source maps): cached by
@@ -437,9 +438,11 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.use_nn = (p.use_grid && nn_on && !ctx->host.nn_cells.empty()) ? 1 : 0;
     p.leaf_order = ctx->host.leaf_order ? 1 : 0;
     p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
+    p.n0_batch = static_cast<int32_t>(ctx->opt_n0_batch);
     p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
     p.uniform_radius = 0;
-    if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2) {  // one radius, bit for bit
+    if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2 &&
+        ctx->host.spheres.size() <= 256) {  // one radius, bit for bit; at most 256 spheres: the scan keys carry the id in eight bits
         const auto &sp = ctx->host.spheres;
         const auto &rd = ctx->host.radii;
         bool same = rd.size() == sp.size();
@@ -491,6 +494,7 @@ int rm_create(int device, rm_ctx **out) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), 40 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, 40 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(ctx->d_stamps + 6, 0xFF, sizeof(unsigned long long));
         if (e != hipSuccess) {
             delete ctx;
             return RM_E_HIP;
@@ -1049,6 +1053,7 @@ int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8) {
     RM_HIP(ctx, hipDeviceSynchronize());
     RM_HIP(ctx, hipMemcpy(out8, ctx->d_stamps, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     RM_HIP(ctx, hipMemset(ctx->d_stamps, 0, 8 * sizeof(uint64_t)));
+    RM_HIP(ctx, hipMemset(ctx->d_stamps + 6, 0xFF, sizeof(uint64_t)));  // slot 6: minimum start time of the next launch's waves
     return RM_OK;
 }
 
@@ -1153,6 +1158,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blocks_per_cu = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "n0_batch")) {
+        if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "n0_batch must be in [1, 64]");
+        ctx->opt_n0_batch = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "length")) {  // part of the numeric contract, not a measurement knob (rm_raymarch.h)
         if (value != 0 && value != 1) return fail(ctx, RM_E_INVALID, "length must be 0 (Math.hypot) or 1 (Math.sqrt)");
         if (ctx->opt_length == value) return RM_OK;
@@ -1188,6 +1198,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;
     else if (!std::strcmp(key, "length")) *value = ctx->opt_length;
+    else if (!std::strcmp(key, "n0_batch")) *value = ctx->opt_n0_batch;
     else return RM_E_INVALID;
     return RM_OK;
 }

@@ -48,6 +48,12 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
         for (int k = 0; k < n; ++k) closest = min_dist(prim_sdf_general(P.prims[ids ? ids[k] : k], p), closest);
         return closest;
     }
+#ifdef RM_REPRO_GENERAL_BRANCH  // round 1's form: the representation chosen by a RUN-TIME branch in the sphere instantiation
+    if (P.general) {
+        for (int k = 0; k < n; ++k) closest = min_dist(prim_sdf_general(P.prims[ids ? ids[k] : k], p), closest);
+        return closest;
+    }
+#endif
     if (P.filter && n >= 2) return prims_min_best<int32_t>(P.spheres, P.radii, ids, n, 0, p, closest);  // scan, then one exact evaluation
     return prims_min<false>(P.spheres, P.radii, ids, n, p, closest, false);
 }

@@ -36,16 +36,25 @@ using namespace rmd;
 // Diagnostic build only (-DRM_STAMPS): per-section cycle shares of the wave loop, accumulated per
 // wave and added to P.stamps[0..7] at the end.  No stamp executes in the product build.
 #ifdef RM_STAMPS
-#define RM_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RM_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();                                                          \
+    if (lane == 0 && P.stamps) atomicMin(&P.stamps[6], t_start_);
 #define RM_T(i)                                                  \
     {                                                            \
         const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
         t_acc_[i] += t_now_ - t_prev_;                           \
         t_prev_ = t_now_;                                        \
     }
+// ... and a histogram of the waves' finishing times (32 buckets of 64 us after the launch's first wave started, read
+// through rm_debug_read_counts): how long is the frame's tail?
 #define RM_TEND()                                                                      \
-    if (lane == 0 && P.stamps)                                                          \
-        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.stamps[i_], t_acc_[i_]);
+    if (lane == 0 && P.stamps) {                                                        \
+        for (int i_ = 0; i_ < 8; ++i_) if (i_ != 6) atomicAdd(&P.stamps[i_], t_acc_[i_]); \
+        const unsigned long long first_ = atomicMin(&P.stamps[6], t_start_);            \
+        const unsigned long long rel_ = __builtin_amdgcn_s_memrealtime() - (first_ < t_start_ ? first_ : t_start_); \
+        unsigned long long b_ = rel_ / 6400ull;  /* 100 MHz: 64 us */                  \
+        atomicAdd(&P.stamps[8 + (b_ > 31 ? 31 : b_)], 1ull);                            \
+    }
 #else
 #define RM_T0()
 #define RM_T(i)
@@ -322,19 +331,26 @@ __device__ double bvh_distance_wave_seq(const RmRenderParams &P, const SceneView
 struct BestScan {
     int k1;
     float hi1, lb1, lb2;
+    uint32_t kbest, ksecond;  // UR: order keys (see scan_sphere)
 };
 // UR (every sphere of the scene has the same radius): distance order = order of the squared centre distances, so
 // the scan ranks by s2 = |p - c|^2 (hi1 holds the smallest, lb2 the smallest of the others) and the square root,
 // the radius and the error margin are applied once, after the scan (scan_finish), instead of once per sphere.
+// UR keys: s2 >= 0, so its bit pattern orders like the value; the low eight mantissa bits give way to the sphere id (UR
+// kernels run scenes of at most 256 spheres), which makes "smallest and its id, and the smallest of the others" three
+// integer min / max instructions with no compare and no select:  lo = min(best, key), hi = max(best, key), second =
+// min(second, hi).  Clearing mantissa bits only lowers a key, so the runner-up's bound stays a lower bound; two spheres
+// closer than 2^-15 (relative, in s2) may be ranked the wrong way round, which the near-tie test after the exact
+// evaluation catches like any other near tie (the wrongly ranked one's lower bound cannot exceed the exact value).
 template <bool UR>
 __device__ __forceinline__ void scan_sphere(BestScan &b, const RmSphere &s, int id, const Vec3f &p) {
     if (UR) {
         const float dx = p.x - s.cx, dy = p.y - s.cy, dz = p.z - s.cz;
         const float s2 = dx * dx + dy * dy + dz * dz;
-        const bool better = s2 < b.hi1;
-        b.lb2 = __builtin_fminf(b.lb2, better ? b.hi1 : s2);
-        b.k1 = better ? id : b.k1;
-        b.hi1 = __builtin_fminf(b.hi1, s2);
+        const uint32_t key = (__float_as_uint(s2) & 0xFFFFFF00u) | static_cast<uint32_t>(id);
+        const uint32_t lo = min(key, b.kbest), hi = max(key, b.kbest);
+        b.kbest = lo;
+        b.ksecond = min(hi, b.ksecond);
         return;
     }
     float err;
@@ -360,18 +376,43 @@ __device__ __forceinline__ void scan_finish_uniform(BestScan &b, float rf) {
 // cell's nearest-candidate list (scene.ts:173) -- feeds ONE scan; the exact FP64 evaluation then happens once per
 // call, for all lanes together, instead of once per list position at which some lane's bound passes.  Near ties
 // (the runner-up's lower bound does not exceed the exact value) are recomputed by the sequential form above.
-template <bool UR>
+// What the fused normal evaluation (render_kernel_v2, section N) needs to know about the evaluation at the hit point:
+// which sphere gave the value, how far every other candidate is at least (binary32 lower bound), how many primitives
+// were counted, and whether the set of leaves that contain the point is the same for every point within NRM_DELTA of it.
+struct NormalAux {
+    int k1;
+    float lb2;
+    uint32_t found;
+    bool ok;
+};
+// The three offset points of getNormal (raymarcher.ts:126-132) are hit - 0.01 e_i, stored as binary32:
+// |q_i - hit| <= 0.01 + half an ulp of a coordinate (< 2^-21 for |x| < 16); the box faces compared against are
+// binary32 and lo - delta / hi + delta round once more.  0.010003 covers all of it with a factor of 100 to spare.
+#define RM_NRM_DELTA 0.010003f
+// true when "box contains q" has the same answer for every point within RM_NRM_DELTA of p along one axis: p is outside by
+// more than delta on some axis, or inside by more than delta on all three
+__device__ __forceinline__ bool box_answer_is_stable(const float lo[3], const float hi[3], const Vec3f &p) {
+    const float d = RM_NRM_DELTA;
+    const bool far_out = p.x < lo[0] - d || p.x > hi[0] + d || p.y < lo[1] - d || p.y > hi[1] + d || p.z < lo[2] - d || p.z > hi[2] + d;
+    const bool deep_in = p.x >= lo[0] + d && p.x <= hi[0] - d && p.y >= lo[1] + d && p.y <= hi[1] - d && p.z >= lo[2] + d && p.z <= hi[2] - d;
+    return far_out || deep_in;
+}
+
+template <bool UR, bool NRM = false>
 __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
                                     uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
-                                    unsigned long long *dbg_fallback_cycles) {
+                                    unsigned long long *dbg_fallback_cycles, NormalAux *aux = nullptr) {
+    if (NRM) aux->ok = false;
     if (!filter) return bvh_distance_wave_seq(P, S, need, q, count, lane, coop, filter, use_grid, dbg_fallback_cycles);
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     bool walk_tree = false;
     bool in_root = false;
+    bool stable = true;  // NRM: the leaf set is the same within RM_NRM_DELTA of q
     BestScan bs;
     bs.k1 = -1;
     bs.hi1 = bs.lb1 = bs.lb2 = __builtin_inff();
+    bs.kbest = bs.ksecond = 0xFFFFFFFFu;
     auto scan_leaf = [&](const RmBvhNode &node) {
         const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
         for (int k = 0; k < cnt; ++k) {
@@ -388,6 +429,7 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
             const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
             in_root = true;
+            if (NRM) stable = box_answer_is_stable(root.lo, root.hi, q);
             const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
             const int ccnt = static_cast<int>(cell & 0xFFu);
             if (ccnt == 255) walk_tree = true;  // crowded cell: the tree walk below
@@ -396,12 +438,14 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
                 for (int e = 0; e < ccnt; ++e) {
                     RM_CNT(7)
                     const RmBvhNode node = S.nodes[lst[e]];
+                    if (NRM) stable = stable && box_answer_is_stable(node.lo, node.hi, q);
                     if (box_contains(node.lo, node.hi, q)) scan_leaf(node);
                 }
             }
         }
     }
     if (need && (!use_grid || walk_tree)) {
+        stable = false;  // the fused normal evaluation relies on the cell's leaf list (grown by RM_NRM_DELTA on the host)
         int i = 0;
         const int n = S.bvh_nodes;
         while (i < n) {  // BVH.getPrimitivesAt (bvh.ts:95-121), stackless
@@ -438,6 +482,10 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
     }
     // the one exact evaluation of this call
     bool redo = false;
+    if (UR && bs.kbest != 0xFFFFFFFFu) {  // decode the keys: best id, and the runner-up's squared distance (rounded down)
+        bs.k1 = static_cast<int>(bs.kbest & 0xFFu);
+        bs.lb2 = bs.ksecond == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(bs.ksecond & 0xFFFFFF00u);
+    }
     if (bs.k1 >= 0) {
         RM_CNT(10)
         const RmSphere s1 = S.spheres[bs.k1];
@@ -445,6 +493,12 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
         closest = sphere_sdf_fast(s1, S.radii[bs.k1], q);
         if (closest > RM_MAX_DIST) closest = RM_MAX_DIST;  // Math.min(sdf, closestDistance = 10)
         redo = bs.lb2 <= f32_upper_bound(closest);
+    }
+    if (NRM) {  // the value came from sphere k1 alone, every other candidate of the (stable) leaf set is at least lb2 away
+        aux->k1 = bs.k1;
+        aux->lb2 = bs.lb2;
+        aux->found = found;
+        aux->ok = need && stable && in_root && found > 0 && bs.k1 >= 0 && !redo;
     }
     if (__any(redo)) {  // near tie somewhere in the wave: those lanes take the sequential form (same result by construction)
         if (redo) RM_CNT(11)
@@ -730,6 +784,83 @@ __device__ bool bvh_next(const SceneView &S, const Ray &r, const RayInv &ri, Ray
 
 // ---- the kernel ------------------------------------------------------------------------------
 
+// Where every staged table lives in LDS: a pure function of the launch parameters (counts), so that any section of
+// the wave loop can rebuild its SceneView from freshly loaded parameters (cold_params) with a handful of scalar
+// instructions, instead of keeping a dozen table addresses and scene constants in SGPRs across the whole loop -- where
+// they do not fit: the first build spilled 130 SGPRs to VGPR lanes and a tenth of the wave loop's straight-line
+// instructions were v_readlane reloads (4.7 issue cycles each, profiles/r02/valu_issue_costs.json).
+struct LdsLayout {
+    uint32_t nodes, prims, cells, list, oct, oct_prims, spheres, radii, rel, end;
+};
+template <int ACCEL, bool LDS, bool REL>
+__device__ __forceinline__ LdsLayout lds_layout(const RmRenderParams &C) {
+    auto up = [](uint32_t v) { return (v + 15u) & ~15u; };
+    auto words = [](uint32_t count, uint32_t size) { return ((count * size + 3u) / 4u) * 4u; };
+    LdsLayout o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t off = 0;
+    if (LDS) {
+        if (ACCEL == 2) {
+            o.nodes = off = up(off);
+            off += words(static_cast<uint32_t>(C.bvh_nodes), sizeof(RmBvhNode));
+            o.prims = off = up(off);
+            off += words(static_cast<uint32_t>(C.bvh_prim_count), 4);
+            o.cells = off = up(off);
+            off += words(static_cast<uint32_t>(C.pq_cell_count), 4);
+            o.list = off = up(off);
+            off += words(static_cast<uint32_t>(C.pq_list_count), 2);
+        } else if (ACCEL == 1) {
+            o.oct = off = up(off);
+            off += words(static_cast<uint32_t>(C.oct_nodes), sizeof(RmOctNode));
+            o.oct_prims = off = up(off);
+            off += words(static_cast<uint32_t>(C.oct_prim_count), 4);
+        }
+        o.spheres = off = up(off);
+        off += words(static_cast<uint32_t>(C.n_prims), sizeof(RmSphere));
+        o.radii = off = up(off);
+        off += words(static_cast<uint32_t>(C.n_prims), 8);
+        off = up(off);
+        if (REL) {
+            o.rel = off;
+            off += static_cast<uint32_t>(C.bvh_nodes) * 48u;
+        }
+    }
+    o.end = off;
+    return o;
+}
+template <int ACCEL, bool LDS, bool REL>
+__device__ __forceinline__ SceneView scene_view(const RmRenderParams &C, unsigned char *smem) {
+    SceneView S;
+    S.nodes = C.bvh;
+    S.bvh_prims = C.bvh_prims;
+    S.oct = C.oct;
+    S.oct_prims = C.oct_prims;
+    S.spheres = C.spheres;
+    S.radii = C.radii;
+    S.pq_cells = C.pq_cells;
+    S.pq_list = C.pq_list;
+    S.nn_cells = C.nn_cells;
+    S.nn_list = C.nn_list;
+    S.rel = nullptr;
+    S.n_prims = C.n_prims;
+    S.bvh_nodes = C.bvh_nodes;
+    if (LDS) {
+        const LdsLayout o = lds_layout<ACCEL, LDS, REL>(C);
+        if (ACCEL == 2) {
+            S.nodes = reinterpret_cast<const RmBvhNode *>(smem + o.nodes);
+            S.bvh_prims = reinterpret_cast<const int32_t *>(smem + o.prims);
+            S.pq_cells = reinterpret_cast<const uint32_t *>(smem + o.cells);
+            S.pq_list = reinterpret_cast<const uint16_t *>(smem + o.list);
+        } else if (ACCEL == 1) {
+            S.oct = reinterpret_cast<const RmOctNode *>(smem + o.oct);
+            S.oct_prims = reinterpret_cast<const int32_t *>(smem + o.oct_prims);
+        }
+        S.spheres = reinterpret_cast<const RmSphere *>(smem + o.spheres);
+        S.radii = reinterpret_cast<const double *>(smem + o.radii);
+        if (REL) S.rel = reinterpret_cast<const double *>(smem + o.rel);
+    }
+    return S;
+}
+
 template <typename T>
 __device__ __forceinline__ const T *stage(unsigned char *smem, size_t &off, const T *src, int count) {
     off = (off + 15) & ~static_cast<size_t>(15);
@@ -806,57 +937,49 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    SceneView S;
-    S.nodes = P.bvh;
-    S.bvh_prims = P.bvh_prims;
-    S.oct = P.oct;
-    S.oct_prims = P.oct_prims;
-    S.spheres = P.spheres;
-    S.radii = P.radii;
-    S.pq_cells = P.pq_cells;
-    S.pq_list = P.pq_list;
-    S.nn_cells = P.nn_cells;
-    S.nn_list = P.nn_list;
-    S.rel = nullptr;
-    S.n_prims = P.n_prims;
-    S.bvh_nodes = P.bvh_nodes;
-    const bool use_grid = ACCEL == 2 && P.use_grid != 0;
-    size_t off = 0;
-    if (LDS) {  // staged once per persistent workgroup
-        if (ACCEL == 2) {
-            S.nodes = stage(smem, off, P.bvh, P.bvh_nodes);
-            S.bvh_prims = stage(smem, off, P.bvh_prims, P.bvh_prim_count);
-            // staged unconditionally: a pointer that is LDS on one path and global on the other is a generic
-            // pointer, and every list read in the leaf loop became a flat_load with a full s_waitcnt
-            S.pq_cells = stage(smem, off, P.pq_cells, P.pq_cell_count);
-            S.pq_list = stage(smem, off, P.pq_list, P.pq_list_count);
-        } else if (ACCEL == 1) {
-            S.oct = stage(smem, off, P.oct, P.oct_nodes);
-            S.oct_prims = stage(smem, off, P.oct_prims, P.oct_prim_count);
-        }
-        S.spheres = stage(smem, off, P.spheres, P.n_prims);
-        S.radii = stage(smem, off, P.radii, P.n_prims);
-        off = (off + 15) & ~static_cast<size_t>(15);
-        if (REL) {  // node boxes relative to this frame's ray origin (slab_rel)
-            double *rel = reinterpret_cast<double *>(smem + off);
-            for (int k = threadIdx.x; k < P.bvh_nodes * 6; k += blockDim.x) {
-                const int node = k / 6, c = k - node * 6;
-                const float v = c < 3 ? P.bvh[node].lo[c] : P.bvh[node].hi[c - 3];
-                rel[k] = static_cast<double>(v) - P.origin_d[c < 3 ? c : c - 3];
+    {   // staged once per persistent workgroup, at the places lds_layout() names
+        const LdsLayout lay = lds_layout<ACCEL, LDS, REL>(P);
+        if (LDS) {
+            size_t off;
+            if (ACCEL == 2) {
+                off = lay.nodes;
+                stage(smem, off, P.bvh, P.bvh_nodes);
+                off = lay.prims;
+                stage(smem, off, P.bvh_prims, P.bvh_prim_count);
+                // staged unconditionally: a pointer that is LDS on one path and global on the other is a generic
+                // pointer, and every list read in the leaf loop became a flat_load with a full s_waitcnt
+                off = lay.cells;
+                stage(smem, off, P.pq_cells, P.pq_cell_count);
+                off = lay.list;
+                stage(smem, off, P.pq_list, P.pq_list_count);
+            } else if (ACCEL == 1) {
+                off = lay.oct;
+                stage(smem, off, P.oct, P.oct_nodes);
+                off = lay.oct_prims;
+                stage(smem, off, P.oct_prims, P.oct_prim_count);
             }
-            S.rel = rel;
-            off += static_cast<size_t>(P.bvh_nodes) * 48;
+            off = lay.spheres;
+            stage(smem, off, P.spheres, P.n_prims);
+            off = lay.radii;
+            stage(smem, off, P.radii, P.n_prims);
+            if (REL) {  // node boxes relative to this frame's ray origin (slab_rel)
+                double *rel = reinterpret_cast<double *>(smem + lay.rel);
+                for (int k = threadIdx.x; k < P.bvh_nodes * 6; k += blockDim.x) {
+                    const int node = k / 6, c = k - node * 6;
+                    const float v = c < 3 ? P.bvh[node].lo[c] : P.bvh[node].hi[c - 3];
+                    rel[k] = static_cast<double>(v) - P.origin_d[c < 3 ? c : c - 3];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
+    const size_t off = lds_layout<ACCEL, LDS, REL>(P).end;
     RayList L;
     L.cap = P.list_cap;
     L.cnt = 0;
     L.live = 0;
     L.cur_pos = 0;
     L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
-    const bool coop = P.coop != 0, filter = P.filter != 0;
-
     const int item_px = P.item_px;
     // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
     int home = P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7);
@@ -976,11 +1099,11 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                         const int r0 = (tile_row << C.tile_h_log2) + batch_sub * (64 >> C.tile_w_log2);
                         const Bundle B = make_bundle(C, x0, x0 + Q.tile_w - 1, row_to_y(C, r0),
                                                      row_to_y(C, r0 + (64 >> C.tile_w_log2) - 1));
-                        const bool hc = bvh_prologue_cull<REL>(S, C, B, in_frame, ray, ri, L, cur, lane);
+                        const bool hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane);
                         if (in_frame) haveCur = hc;
                     } else if (in_frame) {
                         RM_CNT(15)
-                        haveCur = bvh_prologue<REL>(S, ray, ri, L, cur);
+                        haveCur = bvh_prologue<REL>(scene_view<ACCEL, LDS, REL>(C, smem), ray, ri, L, cur);
                     }
 #ifdef RM_STAMPS
                     t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
@@ -1004,6 +1127,10 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
         RM_T(0)
 
         // ---- A: bookkeeping until this lane needs a distance (sphereTracer.ts:43-64) ------
+        // Every section works on a SceneView rebuilt from freshly loaded parameters (see lds_layout): nothing of it
+        // lives in SGPRs across the wave loop.
+        const RmRenderParams CA = cold_params();
+        const SceneView S = scene_view<ACCEL, LDS, REL>(CA, smem);
         bool need = false;
         Vec3f q = {0.f, 0.f, 0.f};
         int onode = -1;
@@ -1060,7 +1187,12 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                 break;
             }
         }
-        if (phase >= PH_N0 && phase <= PH_N3) {  // raymarcher.ts:123-132 sample points
+        // BVH kernels defer getNormal: a ray that has finished marching waits in PH_N0 until no lane of the wave needs a
+        // march distance any more; then all of them take ONE round for the hit point (n0_go) and, where the evaluation
+        // allows it, get the three offset distances from the same sphere without three more rounds (section N below).
+        bool n0_go = true;
+        if (ACCEL == 2) n0_go = !__any(need) || __popcll(__ballot(phase == PH_N0)) >= CA.n0_batch;
+        if (phase >= PH_N0 && phase <= PH_N3 && (phase != PH_N0 || n0_go)) {  // raymarcher.ts:123-132 sample points
             RM_CNT(14)
             q = point_at(ray, t);  // hitPosition (raymarcher.ts:94-95), recomputed: 3 VGPRs fewer
             if (phase == PH_N1) q.x = to_f32(static_cast<double>(q.x) - 0.01);
@@ -1074,25 +1206,37 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
 
         // ---- B: one Scene.getDistance per needing lane --------------------------------------
         if (need) RM_CNT(6)
+        const RmRenderParams CB = cold_params();
+        const SceneView SB = scene_view<ACCEL, LDS, REL>(CB, smem);
+        const bool coop = CB.coop != 0, filter = CB.filter != 0;
+        const bool use_grid = ACCEL == 2 && CB.use_grid != 0;
         double dist;
+        NormalAux aux;
+        aux.ok = false;
+        aux.k1 = 0;
+        aux.lb2 = 0.f;
+        aux.found = 0;
         if (ACCEL == 2) {
 #ifdef RM_STAMPS
             unsigned long long fbc = 0;
-            dist = bvh_distance_wave<UR>(P, S, need, q, count, lane, coop, filter, use_grid, &fbc);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, count, lane, coop, filter, use_grid, &fbc, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, count, lane, coop, filter, use_grid, &fbc);
             t_acc_[4] += fbc;
             t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
 #else
-            dist = bvh_distance_wave<UR>(P, S, need, q, count, lane, coop, filter, use_grid, nullptr);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, count, lane, coop, filter, use_grid, nullptr, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, count, lane, coop, filter, use_grid, nullptr);
 #endif
         }
-        else if (ACCEL == 1) dist = need ? oct_distance_lane(S, onode, q, count, filter) : RM_MAX_DIST;
+        else if (ACCEL == 1) dist = need ? oct_distance_lane(SB, onode, q, count, filter) : RM_MAX_DIST;
         else {
-            dist = all_prims_wave(S, need, q, lane, coop, filter);
-            if (need) count += static_cast<uint32_t>(S.n_prims);
+            dist = all_prims_wave(SB, need, q, lane, coop, filter);
+            if (need) count += static_cast<uint32_t>(SB.n_prims);
         }
 
         RM_T(2)
         // ---- C: consume -------------------------------------------------------------------------
+        const bool fuse = ACCEL == 2 && need && phase == PH_N0 && aux.ok;
         if (need) {
             if (phase == PH_MARCH) {
                 t += dist;
@@ -1111,6 +1255,33 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                 nz = to_f32(d0 - dist);
                 normalize3(nx, ny, nz);
                 phase = PH_DONE;
+            }
+        }
+        // ---- N: the three offset samples of getNormal (raymarcher.ts:126-132) from the sphere that gave d0.  The leaf
+        // set is the same at the offset points (aux.ok: box_answer_is_stable for every listed leaf and the root), so the
+        // same spheres are the candidates there and the counter advances by the same number; Sphere.sdf is 1-Lipschitz, so
+        // every candidate other than k1 is at least lb2 - delta away at an offset point.  If that exceeds the exact distance
+        // of k1 there, k1 is the minimum (Math.min is order independent): three exact evaluations replace three rounds.
+        // A lane for which one of the three checks fails keeps d0 and goes on through PH_N1..PH_N3 as before.
+        if (ACCEL == 2 && __any(fuse)) {
+            if (fuse) {
+                const SceneView SN = scene_view<ACCEL, LDS, REL>(cold_params(), smem);
+                const RmSphere s1 = SN.spheres[aux.k1];
+                const double r1 = SN.radii[aux.k1];
+                Vec3f qx = q, qy = q, qz = q;
+                qx.x = to_f32(static_cast<double>(q.x) - 0.01);
+                qy.y = to_f32(static_cast<double>(q.y) - 0.01);
+                qz.z = to_f32(static_cast<double>(q.z) - 0.01);
+                const double e1 = sphere_sdf_fast(s1, r1, qx), e2 = sphere_sdf_fast(s1, r1, qy), e3 = sphere_sdf_fast(s1, r1, qz);
+                const double emax = __builtin_fmax(__builtin_fmax(e1, e2), e3);
+                if (aux.lb2 - RM_NRM_DELTA > f32_upper_bound(emax)) {
+                    count += 3u * aux.found;
+                    nx = to_f32(d0 - __builtin_fmin(e1, RM_MAX_DIST));  // Math.min(sdf, closestDistance = 10)
+                    ny = to_f32(d0 - __builtin_fmin(e2, RM_MAX_DIST));
+                    nz = to_f32(d0 - __builtin_fmin(e3, RM_MAX_DIST));
+                    normalize3(nx, ny, nz);
+                    phase = PH_DONE;
+                }
             }
         }
         RM_T(3)

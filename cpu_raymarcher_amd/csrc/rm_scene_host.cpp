@@ -202,8 +202,11 @@ void build_point_query_grid(HostScene &s) {
         if (nd.leaf < 0 || (nd.leaf & 0xFF) == 0) continue;
         int c0[3], c1[3];
         for (int k = 0; k < 3; ++k) {
-            const double a = (double(nd.lo[k]) - double(s.pq_origin[k])) * double(s.pq_inv[k]) - 0.01;
-            const double b = (double(nd.hi[k]) - double(s.pq_origin[k])) * double(s.pq_inv[k]) + 0.01;
+            // + 0.0101 in world units: the v2 kernel's fused normal evaluation asks, from the cell of the hit point, about
+            // the three points 0.01 beside it (raymarcher.ts:126-132; rm_render_v2.hip RM_NRM_DELTA), so a cell also lists
+            // every leaf that can contain a point within that distance of the cell
+            const double a = (double(nd.lo[k]) - 0.0101 - double(s.pq_origin[k])) * double(s.pq_inv[k]) - 0.01;
+            const double b = (double(nd.hi[k]) + 0.0101 - double(s.pq_origin[k])) * double(s.pq_inv[k]) + 0.01;
             c0[k] = std::max(0, std::min(s.pq_dim[k] - 1, static_cast<int>(std::floor(a))));
             c1[k] = std::max(0, std::min(s.pq_dim[k] - 1, static_cast<int>(std::floor(b))));
         }

@@ -128,6 +128,7 @@ struct RmRenderParams {
     int32_t stripe_rows;       // > 0: rows are dealt in stripes of this many rows, round-robin over n_parts;
     int32_t n_parts, part;     //      this launch renders the stripes of `part`, packed in increasing y
     int32_t rel_boxes;         // v2: stage origin-relative node boxes (doubles) in LDS when they fit (option `rel`)
+    int32_t n0_batch;          // v2 BVH: lanes waiting for getNormal that trigger the normal round while others still march (64: never)
     const int32_t *stripe_ids; // non-null (with stripe_rows > 0): the launch renders the stripes stripe_ids[0 .. ) in this
                                // order (increasing), packed; any deal of stripes to parts, e.g. a weighted one
     unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch

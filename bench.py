@@ -285,6 +285,9 @@ def main():
     in_flight_opts = {}  # option -> (value with frames in flight, library default used by serial launches)
     if S > 1:
         in_flight_opts["blocks_per_cu"] = (1, ctx.get_option("blocks_per_cu"))
+        # longest-first item order (lpt) shortens the tail of a frame that runs ALONE; overlapping frames hide that tail
+        # anyway and the extra sort kernel per launch costs ~1 %
+        in_flight_opts["lpt"] = (0, ctx.get_option("lpt"))
         if world == 1:  # whole frames: 256-pixel work items of 8 x 32 pixels
             in_flight_opts["item_px"] = (256, ctx.get_option("item_px"))
             in_flight_opts["tile_w"] = (8, ctx.get_option("tile_w"))
@@ -527,7 +530,7 @@ def main():
 
     # The launch running ALONE (library defaults, serial, HIP events around each launch) and the strictly serial frame
     # rate (render + reduce back to back on one stream), both right after the timed region.  N = 1 only.
-    kern_ms, value_serial, kernel_alone = kern_ms_in_flight, None, kernel_in_flight
+    kern_ms, value_serial, kernel_alone, kern_ms_cold = kern_ms_in_flight, None, kernel_in_flight, None
     if world == 1 and not args.analytics_sweep:
         b = sets[0]
         apply_opts(False)
@@ -543,6 +546,7 @@ def main():
                 torch.cuda.synchronize()
             kernel_alone = ctx.last_kernel()
             kern_ms = sum(a.elapsed_time(c) for a, c in ser[2:]) / len(ser[2:])
+            kern_ms_cold = ser[0][0].elapsed_time(ser[0][1])  # first launch after the option switch: no item costs recorded yet
             n_ser = max(5, min(20, args.steps))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -589,11 +593,14 @@ def main():
             "sphere_evals_per_s": d["total_sdf"] * fps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "pmc_source": pmc_note,
-                         "kernel": kernel_alone, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": kernel_alone, "kernel_ms": kern_ms, "kernel_ms_first_launch": kern_ms_cold,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "basis": "the launch ALONE: algorithmic bytes per launch / mean duration of %s (HIP events on the "
-                                  "launch stream)" % ("serial launches with the library's default options, right after the "
-                                                      "timed region" if world == 1 and not args.analytics_sweep else
-                                                      "the timed region's launches"),
+                                  "launch stream)" % ("six serial launches of the same frame with the library's default options, right "
+                                                      "after the timed region; by default (option lpt) a launch hands out its work "
+                                                      "items longest-first using the item costs the previous launch recorded -- "
+                                                      "kernel_ms_first_launch is the launch without such costs"
+                                                      if world == 1 and not args.analytics_sweep else "the timed region's launches"),
                          "achieved_in_flight": achieved_in_flight, "frac_in_flight": achieved_in_flight / HBM_PEAK_GBPS,
                          "kernel_in_flight": kernel_in_flight, "kernel_ms_in_flight": kern_ms_in_flight,
                          "frames_in_flight": S, "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},

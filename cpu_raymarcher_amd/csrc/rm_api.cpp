@@ -92,6 +92,16 @@ struct rm_ctx {
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
+    int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's costs (shortens the tail of a frame that runs alone)
+    // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
+    // permutation and records its own costs); geometry changes restart the feedback
+    static constexpr int kLptSlots = 16;
+    static constexpr int kLptStride = 16384;  // items per XCD queue (8 queues); larger frames render without LPT
+    uint8_t *d_lpt_cost = nullptr;    // [kLptSlots][8 * kLptStride]
+    uint16_t *d_lpt_perm = nullptr;   // [kLptSlots][8 * kLptStride]
+    unsigned int lpt_launch = 0;
+    long long lpt_geometry = -1;
+    hipEvent_t lpt_done[16] = {};  // recorded after the launch that owns the slot: a slot is reused only once that launch is over
     int64_t opt_n0_batch = 64;  // v2 BVH: see RmRenderParams::n0_batch
     int64_t opt_length = 0;  // vec3.length: 0 Math.hypot (gl-matrix 3.0 - 3.4.3), 1 Math.sqrt(x*x + y*y + z*z)
     const char *last_kernel = "";
@@ -122,8 +132,40 @@ int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
 }
 
 // the kernels exist twice: vec3.length = Math.hypot, and = sqrt(x*x + y*y + z*z) (rm_kernels.h, option `length`)
-hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p, hipStream_t stream) {
-    return ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t stream) {
+    RmRenderParams p = p_in;
+    if (ctx->opt_lpt && p.variant == 2 && p.algorithm == 0) {  // longest-first item order (rm_render_v2.hip, lpt_sort_kernel)
+        const size_t per_slot = static_cast<size_t>(8) * rm_ctx::kLptStride;
+        if (!ctx->d_lpt_cost) {
+            if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lpt_cost), rm_ctx::kLptSlots * per_slot) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&ctx->d_lpt_perm), rm_ctx::kLptSlots * per_slot * sizeof(uint16_t)) != hipSuccess) {
+                (void)hipFree(ctx->d_lpt_cost);
+                ctx->d_lpt_cost = nullptr;
+                ctx->d_lpt_perm = nullptr;
+            }
+        }
+        if (ctx->d_lpt_cost) {
+            // the costs are per item of THIS tiling of THIS row set: any change restarts the feedback (costs read as zero)
+            const long long geom = ((static_cast<long long>(p.width) * 65536 + p.local_rows) * 1024 + p.tile_w) * 1024 + p.item_px +
+                                   (p.stripe_rows ? (1ll << 62) + p.part * 131 + p.n_parts : 0) + p.y_start * 7919ll;
+            const unsigned slot = ctx->lpt_launch % rm_ctx::kLptSlots, prev = (ctx->lpt_launch + rm_ctx::kLptSlots - 1) % rm_ctx::kLptSlots;
+            const bool have_prev = ctx->lpt_launch > 0 && geom == ctx->lpt_geometry;
+            ctx->lpt_geometry = geom;
+            ctx->lpt_launch++;
+            if (ctx->lpt_done[slot]) (void)hipEventSynchronize(ctx->lpt_done[slot]);  // 16 launches ago: normally long finished
+            p.lpt_stride = rm_ctx::kLptStride;
+            p.lpt_cost_prev = have_prev ? ctx->d_lpt_cost + prev * per_slot : nullptr;
+            p.lpt_cost_out = ctx->d_lpt_cost + slot * per_slot;
+            p.lpt_perm_out = ctx->d_lpt_perm + slot * per_slot;
+        }
+    }
+    const hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+    if (e == hipSuccess && p.lpt_perm_out) {
+        const unsigned slot = (ctx->lpt_launch + rm_ctx::kLptSlots - 1) % rm_ctx::kLptSlots;
+        if (!ctx->lpt_done[slot]) (void)hipEventCreateWithFlags(&ctx->lpt_done[slot], hipEventDisableTiming);
+        if (ctx->lpt_done[slot]) (void)hipEventRecord(ctx->lpt_done[slot], stream);
+    }
+    return e;
 }
 
 #define RM_HIP(ctx, call)                                       \
@@ -520,6 +562,10 @@ void rm_destroy(rm_ctx *ctx) {
         (void)hipFree(ctx->d_counters);
         (void)hipFree(ctx->d_stamps);
         for (auto &t : ctx->tables) (void)hipFree(t.dev);
+        (void)hipFree(ctx->d_lpt_cost);
+        (void)hipFree(ctx->d_lpt_perm);
+        for (hipEvent_t ev : ctx->lpt_done)
+            if (ev) (void)hipEventDestroy(ev);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1158,6 +1204,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blocks_per_cu = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "lpt")) {
+        ctx->opt_lpt = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "n0_batch")) {
         if (value < 1 || value > 64) return fail(ctx, RM_E_INVALID, "n0_batch must be in [1, 64]");
         ctx->opt_n0_batch = value;
@@ -1199,6 +1249,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;
     else if (!std::strcmp(key, "length")) *value = ctx->opt_length;
     else if (!std::strcmp(key, "n0_batch")) *value = ctx->opt_n0_batch;
+    else if (!std::strcmp(key, "lpt")) *value = ctx->opt_lpt;
     else return RM_E_INVALID;
     return RM_OK;
 }

@@ -51,6 +51,9 @@ hipError_t rm_launch_distance(const RmRenderParams &p, const float *points, int6
 hipError_t rm_launch_distance_sqrt(const RmRenderParams &p, const float *points, int64_t n, double *dist,
                                    uint32_t *count, hipStream_t stream);
 
+// v2: builds the longest-first item order of the next launch from the previous launch's recorded costs (rm_render_v2.hip)
+hipError_t rm_launch_lpt_sort(const uint8_t *cost_prev, uint16_t *perm, int stride, int tiles_x, int tiles_y, hipStream_t stream);
+
 // Rank 0 of a sharded frame (rm_frame_ops.hip): copies every stripe of a gathered [world x rank_stride] buffer to its
 // place in the row-major frame and combines the ranks' partial diagnostics accumulators.
 hipError_t rm_launch_assemble(const unsigned char *gathered, int64_t rank_stride, int64_t section_offset, int32_t row_bytes,

@@ -55,7 +55,7 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
     }
 #endif
     if (P.filter && n >= 2) return prims_min_best<int32_t>(P.spheres, P.radii, ids, n, 0, p, closest);  // scan, then one exact evaluation
-    return prims_min<false>(P.spheres, P.radii, ids, n, p, closest, false);
+    return prims_min<true>(P.spheres, P.radii, ids, n, p, closest, false);  // shared-reciprocal Math.hypot (bit-identical: rm_selftest_fastdiv)
 }
 
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted

@@ -882,6 +882,8 @@ struct TileQueue {
     int tiles_x, tiles_y, tile_w, tile_h, item_px;
     unsigned int tiles_x_magic;  // floor(2^32 / tiles_x) + 1; 0 for tiles_x == 1
     unsigned int base;           // first queue entry handed out dynamically (the ones before it are assigned statically)
+    const uint16_t *perm;        // longest-first order of every queue (null: the queue's own order), lpt_stride entries apart
+    int perm_stride;
 };
 
 // next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
@@ -889,8 +891,12 @@ struct TileQueue {
 // they are handed out from the middle of the frame outwards, so the light rows near the top and bottom edges (rays that
 // miss everything) come last and pack the frame's tail.
 __device__ __forceinline__ bool queue_entry(const TileQueue &Q, int x, unsigned int k, int &tile_col, int &tile_row) {
-    const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
     const int R = (Q.tiles_y - x + 7) >> 3;
+    if (Q.perm) {  // the k-th item to hand out is the one the previous frame found k-th longest (any permutation is valid)
+        if (k >= static_cast<unsigned int>(R) * static_cast<unsigned int>(Q.tiles_x)) return false;
+        k = Q.perm[static_cast<size_t>(x) * Q.perm_stride + k];
+    }
+    const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
     const int qi = static_cast<int>(q), mid = R >> 1;
     const int j = (qi & 1) ? mid - ((qi + 1) >> 1) : mid + (qi >> 1);
     tile_row = j * 8 + x;
@@ -933,7 +939,10 @@ __device__ __forceinline__ RmRenderParams cold_params() {
 
 template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 // 96 VGPRs without spills (since the Phong pow left the kernel): five waves per SIMD when the LDS footprint allows
-__global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams P) {
+// (the REL instantiations keep six more doubles' worth of addressing live in the slab tests: at five waves they spill
+// VGPRs to scratch -- and gave wrong pixels with it, non-deterministically, in the build that first did -- so they are
+// compiled for four waves per SIMD; the launcher only picks them where the LDS budget leaves room, i.e. small scenes)
+__global__ __launch_bounds__(256, REL ? 4 : 5) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -986,9 +995,10 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
     const int refill_at = P.refill_threshold;  // refill as soon as this many lanes are idle
 
     // ---- wave state: the tile being consumed ------------------------------------------------
-    int tile_col = 0, tile_row = 0, qpos = item_px;  // qpos: next pixel of the current tile (item_px = used up)
+    int tile_col = -1, tile_row = 0, qpos = item_px;  // tile_col < 0: no item yet; qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
     int static_j = 0;
+    unsigned int item_iters = 0;  // cost feedback for the next frame's longest-first order: wave-loop iterations spent on the current item
 
     // ---- lane state ------------------------------------------------------------------------
     Ray ray;  // set by the first refill (every lane starts idle)
@@ -1024,6 +1034,7 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
     for (;;) {
         RM_T(7)
         RM_CNT(0)
+        item_iters += 1;
         // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
         // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
         const unsigned long long idle = __ballot(phase == PH_DONE);
@@ -1040,6 +1051,8 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
             Q.tiles_y = C.tiles_y;
             Q.tiles_x_magic = C.tiles_x_magic;
             Q.base = static_cast<unsigned int>(C.queue_base);
+            Q.perm = C.lpt_perm;
+            Q.perm_stride = C.lpt_stride;
             // The queue atomic is issued BEFORE the pixel stores and its result consumed after them: the wait for the
             // returned value (s_waitcnt vmcnt counts in order) then no longer covers the completion of the seven stores,
             // which was 23 % of the wave cycles in the stamps build.
@@ -1051,6 +1064,13 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                 store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;
             }
+            if (want_tile && C.lpt_cost_out && tile_col >= 0) {  // the item just finished: what it cost.  Its place in its queue
+                // follows from its tile: the queue is the one it was pulled from (= home), the row slot inverts queue_entry
+                const int R = (Q.tiles_y - home + 7) >> 3, j = tile_row >> 3, mid = R >> 1;
+                const int qi = j >= mid ? 2 * (j - mid) : 2 * (mid - j) - 1;
+                if (lane == 0) C.lpt_cost_out[static_cast<size_t>(home) * C.lpt_stride + static_cast<size_t>(qi) * Q.tiles_x + tile_col] =
+                    static_cast<uint8_t>(item_iters < 255u ? item_iters : 255u);
+            }
             if (want_static) {  // no atomic: workgroup b serves queue b % 8 (the XCD it is dispatched to under round-robin
                                 // placement; coverage does not depend on that), its wave w the entries rank + waves/8 * j
                 const int x = static_cast<int>(blockIdx.x) & 7;
@@ -1060,8 +1080,10 @@ __global__ __launch_bounds__(256, 5) void render_kernel_v2(const RmRenderParams 
                 queue_entry(Q, x, k, tile_col, tile_row);
                 qpos = 0;
             } else if (want_tile) {
-                if (pull_tile(Q, home, tile_col, tile_row, lane, claim)) qpos = 0;
-                else no_more = true;
+                if (pull_tile(Q, home, tile_col, tile_row, lane, claim)) {
+                    qpos = 0;
+                    item_iters = 0;
+                } else no_more = true;
             }
             if (!no_more) {
                 const int remaining = Q.item_px - qpos;
@@ -1308,6 +1330,71 @@ size_t scene_lds_bytes(const RmRenderParams &p) {
 
 }  // namespace
 
+#ifndef RM_LENGTH_SQRT
+namespace {
+// Longest-first order of a frame's work items from the costs the PREVIOUS frame recorded (lpt_cost_prev; a frame loop renders
+// nearly the same picture again, and any permutation is a valid order, so stale or missing costs only cost balance).
+// A frame that runs alone ends with a ramp: its 4096 waves finish over the last ~0.5 ms (scripts/tail_hist.py), because a
+// wave's last item may be one with a 100-step grazing ray.  Handing out the expensive items first leaves cheap ones for the
+// end.  One workgroup per XCD queue; four cost classes (>= 4, 2, 1.25 x the mean, the rest) and a STABLE partition, so that
+// inside a class the queue keeps its own order -- horizontally adjacent tiles stay adjacent in time and their partial-line
+// stores still merge in L2.  The costs are copied to LDS first: the previous launch may still be writing them, and the
+// permutation must be built from ONE snapshot to be a permutation.
+__global__ __launch_bounds__(1024) void lpt_sort_kernel(const uint8_t *cost_prev, uint16_t *perm, int stride, int tiles_x, int tiles_y) {
+    extern __shared__ unsigned char lpt_smem[];
+    const int x = blockIdx.x;
+    const int R = (tiles_y - x + 7) >> 3;
+    const int n = R * tiles_x;
+    uint8_t *cost = lpt_smem;                                                   // n bytes
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(lpt_smem + ((stride + 15) & ~15));  // [4][1024]
+    __shared__ unsigned int sum_s, nz_s, base_s[4];
+    if (threadIdx.x == 0) sum_s = nz_s = 0;
+    __syncthreads();
+    unsigned int sum = 0, nz = 0;
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const uint8_t c = cost_prev ? cost_prev[static_cast<size_t>(x) * stride + e] : 0;
+        cost[e] = c;
+        sum += c;
+        nz += c != 0;
+    }
+    atomicAdd(&sum_s, sum);
+    atomicAdd(&nz_s, nz);
+    __syncthreads();
+    const float mean = nz_s ? static_cast<float>(sum_s) / static_cast<float>(nz_s) : 1e9f;
+    auto cls = [&](uint8_t c) { const float f = c; return f >= 4.f * mean ? 0 : (f >= 2.f * mean ? 1 : (f >= 1.25f * mean ? 2 : 3)); };
+    const int chunk = (n + 1023) / 1024, e0 = threadIdx.x * chunk, e1 = min(n, e0 + chunk);
+    unsigned int mine[4] = {0, 0, 0, 0};
+    for (int e = e0; e < e1; ++e) mine[cls(cost[e])]++;
+    for (int c = 0; c < 4; ++c) cnt[c * 1024 + threadIdx.x] = mine[c];
+    __syncthreads();
+    if (threadIdx.x < 4) {  // exclusive scan of one class over the 1024 chunks
+        unsigned int run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const unsigned int v = cnt[threadIdx.x * 1024 + t];
+            cnt[threadIdx.x * 1024 + t] = run;
+            run += v;
+        }
+        base_s[threadIdx.x] = run;  // class total
+    }
+    __syncthreads();
+    unsigned int start[4], acc = 0;
+    for (int c = 0; c < 4; ++c) {
+        start[c] = acc + cnt[c * 1024 + threadIdx.x];
+        acc += base_s[c];
+    }
+    for (int e = e0; e < e1; ++e) {
+        const int c = cls(cost[e]);
+        perm[static_cast<size_t>(x) * stride + start[c]++] = static_cast<uint16_t>(e);
+    }
+}
+}  // namespace
+hipError_t rm_launch_lpt_sort(const uint8_t *cost_prev, uint16_t *perm, int stride, int tiles_x, int tiles_y, hipStream_t stream) {
+    const size_t shmem = static_cast<size_t>((stride + 15) & ~15) + 4 * 1024 * sizeof(unsigned int);
+    hipLaunchKernelGGL(lpt_sort_kernel, dim3(8), dim3(1024), shmem, stream, cost_prev, perm, stride, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+#endif
+
 hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipStream_t stream, const char **kernel_name) {
     RmRenderParams p = p_in;
     const int rows = p.local_rows;
@@ -1377,6 +1464,20 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
     }
     hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
+    // longest-first item order (option `lpt`): the api layer hands in the cost / permutation buffers and their stride
+    p.lpt_perm = nullptr;
+    if (p.lpt_perm_out && p.static_per_wave == 0) {
+        const long long per_queue = static_cast<long long>((tiles_y + 7) / 8) * tiles_x;
+        if (per_queue <= p.lpt_stride && per_queue <= 32768) {
+            e = rm_launch_lpt_sort(p.lpt_cost_prev, p.lpt_perm_out, p.lpt_stride, tiles_x, tiles_y, stream);
+            if (e != hipSuccess) return e;
+            p.lpt_perm = p.lpt_perm_out;
+        } else {
+            p.lpt_cost_out = nullptr;
+        }
+    } else {
+        p.lpt_cost_out = nullptr;
+    }
     const dim3 grid(blocks), block(256);
 #define RM_V2X(A, L, U, R)                                                                                  \
     {                                                                                                       \

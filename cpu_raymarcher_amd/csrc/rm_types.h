@@ -128,6 +128,14 @@ struct RmRenderParams {
     int32_t stripe_rows;       // > 0: rows are dealt in stripes of this many rows, round-robin over n_parts;
     int32_t n_parts, part;     //      this launch renders the stripes of `part`, packed in increasing y
     int32_t rel_boxes;         // v2: stage origin-relative node boxes (doubles) in LDS when they fit (option `rel`)
+    // v2 longest-first item order from the previous frame's costs (rm_render_v2.hip, lpt_sort_kernel): entry k of queue x is
+    // item lpt_perm[x * lpt_stride + k] of that queue (null: the queue's own order); every finished item's cost (wave-loop
+    // iterations, saturated at 255) goes to lpt_cost_out[x * lpt_stride + item]
+    const uint16_t *lpt_perm;
+    uint8_t *lpt_cost_out;
+    const uint8_t *lpt_cost_prev;
+    uint16_t *lpt_perm_out;  // what the sort kernel of this launch writes (== lpt_perm)
+    int32_t lpt_stride, lpt_pad;
     int32_t n0_batch;          // v2 BVH: lanes waiting for getNormal that trigger the normal round while others still march (64: never)
     const int32_t *stripe_ids; // non-null (with stripe_rows > 0): the launch renders the stripes stripe_ids[0 .. ) in this
                                // order (increasing), packed; any deal of stripes to parts, e.g. a weighted one

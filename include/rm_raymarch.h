@@ -336,6 +336,11 @@ RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
  *   rel 0|1       BVH node boxes relative to the frame's ray origin, as doubles in LDS, when they fit (v2, default 1)
  *   cull 0|1      whole 64-pixel batches find their hit BVH leaves by a bundle-frustum cull (v2, <= 256 leaves, default 1)
  *   lds_kb 16..64 LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (32: five workgroups per CU; 40: four)
+ *   n0_batch 1..64 BVH (v2): getNormal is deferred until no lane of the wave needs a march distance, then evaluated for all waiting
+ *                 rays in one round, the three offset samples taken from the sphere that gave d0 where provably the minimum;
+ *                 lanes waiting that trigger that round early (64: never early; default 64)
+ *   lpt 0|1       v2: hand out a launch's work items longest-first using the item costs the previous launch recorded (any
+ *                 order gives the same bytes; shortens the tail of a frame that runs alone; default 1)
  * The one option that is NOT a measurement knob but part of the numeric contract:
  *   length 0|1    gl-matrix vec3.length / vec3.distance (sphere.ts:12-14, box.ts:26,33, mandelbulb.ts:46, smoothUnion.ts:45):
  *                 0 = Math.hypot(x, y, z) (gl-matrix 3.0 - 3.4.3, default), 1 = Math.sqrt(x*x + y*y + z*z) (the form a later

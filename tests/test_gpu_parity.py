@@ -97,9 +97,12 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, nn=1, coop=0), dict(kernel=2, uniform=0), dict(kernel=2, uniform=0, list_cap=2),
                      dict(kernel=2, rel=0), dict(kernel=2, rel=0, uniform=0), dict(kernel=2, rel=1, list_cap=2),
                      dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16),
-                     dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0)]:
+                     dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0),
+                     dict(kernel=2, n0_batch=1), dict(kernel=2, n0_batch=16, refill=24), dict(kernel=2, n0_batch=8, uniform=0, cull=0),
+                     dict(kernel=2, lpt=0), dict(kernel=2, lpt=1), dict(kernel=2, lpt=1, item_px=64, tile_w=32)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32, cull=1).items():
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32, cull=1,
+                             n0_batch=64, lpt=1).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -839,3 +842,58 @@ def test_vec3_length_modes_differ_and_switch_back(rm, gpu_ctx, oracle):
     finally:
         L.ro_set_length_mode(0)
     assert np.array_equal(d_sqrt[:3000], want)
+
+
+
+def test_longest_first_item_order_is_only_an_order(rm, oracle):
+    """Option `lpt`: a launch hands out its work items longest-first from the costs the PREVIOUS launch recorded.  Any
+    permutation must give the same bytes: the same frame repeated (feedback from an identical frame), a moving camera
+    (stale costs), a change of frame size and of row range (feedback restarts), row stripes, and frames in flight on
+    several streams (a launch sorts while the previous one is still writing its costs)."""
+    import torch
+    ctx = rm.Context(0)
+    ctx.set_option("kernel", 2)
+    dev = torch.device("cuda:0")
+
+    def render(W, H, ang, rows=None, lpt=1):
+        ctx.set_option("lpt", lpt)
+        return gpu_render(rm, ctx, 3, "BVH", W, H, ang, rows=rows)
+
+    ref = {}
+    for lpt in (0, 1, 1, 1):  # the third and fourth launches use the costs of an identical frame
+        got = render(640, 360, (0.1, 0.3), lpt=lpt)
+        ref.setdefault("a", got)
+        assert_same(got, ref["a"], "repeated frame, lpt=%d" % lpt)
+    assert_same(ref["a"], cpu_render(oracle, 3, "BVH", 640, 360, (0.1, 0.3)), "vs oracle")
+    for k in range(6):  # moving camera: costs one frame stale
+        ang = (0.1 + 0.05 * k, 0.3 + 0.2 * k)
+        assert_same(render(640, 360, ang, lpt=1), render(640, 360, ang, lpt=0), "moving camera %d" % k)
+    for (W, H, rows) in ((333, 77, None), (640, 360, (100, 300)), (640, 360, (0, 17)), (1920, 1080, None), (640, 360, None)):
+        assert_same(render(W, H, (0.2, 0.5), rows, lpt=1), render(W, H, (0.2, 0.5), rows, lpt=0), "geometry change %dx%d %r" % (W, H, rows))
+    # frames in flight: 6 streams x 4 rounds, alternating two cameras; every buffer set must hold its own frame
+    ctx.set_option("lpt", 1)
+    W, H = 1280, 720
+    scene = rm.Scene("BVH", ctx=ctx)
+    scene.loadPreset(3)
+    tracer = rm.SphereTracer()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(6)]
+    sets = [dict(d=torch.zeros(W * H, dtype=torch.uint8, device=dev), n=torch.zeros(3 * W * H, dtype=torch.uint8, device=dev),
+                 s=torch.zeros(W * H, dtype=torch.int16, device=dev), i=torch.zeros(W * H, dtype=torch.int16, device=dev)) for _ in range(6)]
+    for rnd in range(4):
+        for k in range(6):
+            scene.camera.setAngles(0.1 * (k % 2), 0.4 * (k % 2))
+            with torch.cuda.stream(streams[k]):
+                tracer.runRaymarcher(scene, sets[k]["d"], sets[k]["n"], sets[k]["s"], sets[k]["i"], W, H, 0.0)
+    torch.cuda.synchronize()
+    for k in range(2, 6):
+        for name in sets[k]:
+            assert torch.equal(sets[k][name], sets[k % 2][name]), (k, name)
+    ctx.set_option("lpt", 0)
+    for k in range(2):
+        scene.camera.setAngles(0.1 * k, 0.4 * k)
+        b = {n: torch.zeros_like(v) for n, v in sets[k].items()}
+        tracer.runRaymarcher(scene, b["d"], b["n"], b["s"], b["i"], W, H, 0.0)
+        torch.cuda.synchronize()
+        for name in b:
+            assert torch.equal(b[name], sets[k][name]), (k, name)
+    ctx.close()

@@ -92,6 +92,7 @@ struct rm_ctx {
     int64_t opt_uniform = 1;  // v2: scenes whose spheres all have one radius rank candidates by squared centre distance
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
+    int64_t opt_v1_lists = 1;  // v1 BVH kernels: per-ray hit-leaf lists instead of one tree walk per interval advance
     int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's costs (shortens the tail of a frame that runs alone)
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
     // permutation and records its own costs); geometry changes restart the feedback
@@ -481,6 +482,10 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.leaf_order = ctx->host.leaf_order ? 1 : 0;
     p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
     p.n0_batch = static_cast<int32_t>(ctx->opt_n0_batch);
+    p.v1_lists = static_cast<int32_t>(ctx->opt_v1_lists);
+    p.v1_list_offset = -1;
+    p.prim_filter = (ctx->opt_filter && ctx->host.general && !ctx->host.program && ctx->host.prim_filter_ok &&
+                     ctx->host.spheres.size() == ctx->host.prims.size()) ? 1 : 0;
     p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2 &&
@@ -1204,6 +1209,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_blocks_per_cu = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "v1_lists")) {
+        ctx->opt_v1_lists = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "lpt")) {
         ctx->opt_lpt = value ? 1 : 0;
         return RM_OK;
@@ -1250,6 +1259,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "length")) *value = ctx->opt_length;
     else if (!std::strcmp(key, "n0_batch")) *value = ctx->opt_n0_batch;
     else if (!std::strcmp(key, "lpt")) *value = ctx->opt_lpt;
+    else if (!std::strcmp(key, "v1_lists")) *value = ctx->opt_v1_lists;
     else return RM_E_INVALID;
     return RM_OK;
 }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rm_device.h"
+#include "rm_bvh_list.h"
 #include "rm_program.h"
 #include "rm_kernels.h"
 
@@ -59,10 +60,37 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
 }
 
 // scene.ts:183-189 and the BVH fallback scene.ts:173: every primitive, all counted
+// General primitives: the reference evaluates all N (scene.ts:173,183-189); with rigid transforms every primitive has a
+// bounding sphere (centre c, radius R; host: build_scene_general) with |p - c| - R <= sdf(p) <= |p - c| + R, so a primitive
+// whose lower bound exceeds the smallest upper bound (or 10, the starting value of `closest`) cannot attain
+// min(10, min_j sdf_j(p)).  Binary32 bounds with the same error margin as the spheres' filter (sphere_sdf_estimate); only
+// the survivors -- a handful of 40 -- are evaluated exactly (transformMat4 + Box / Torus / Sphere localSdf in binary64).
+// Math.min is order independent, so the value is bit-identical; all N are counted.
+__device__ double general_prims_filtered(const RmRenderParams &P, const Vec3f &p) {
+    float ub = 10.0f;
+    for (int j = 0; j < P.n_prims; ++j) {
+        const RmSphere b = P.spheres[j];
+        const float dx = p.x - b.cx, dy = p.y - b.cy, dz = p.z - b.cz;
+        const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+        const float hi = (len + b.rf) + (len + b.rf + 1.0f) * 4e-6f;
+        ub = hi < ub ? hi : ub;
+    }
+    double closest = RM_MAX_DIST;
+    for (int j = 0; j < P.n_prims; ++j) {
+        const RmSphere b = P.spheres[j];
+        const float dx = p.x - b.cx, dy = p.y - b.cy, dz = p.z - b.cz;
+        const float len = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+        const float lo = (len - b.rf) - (len + b.rf + 1.0f) * 4e-6f;
+        if (lo <= ub) closest = min_dist(prim_sdf_general(P.prims[j], p), closest);
+    }
+    return closest;
+}
+
 template <int GEN>
 __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
     double closest = RM_MAX_DIST;
-    closest = list_min<GEN>(P, nullptr, P.n_prims, p, closest);
+    if (GEN == 1 && P.prim_filter && P.n_prims >= 8) closest = general_prims_filtered(P, p);
+    else closest = list_min<GEN>(P, nullptr, P.n_prims, p, closest);
     count += static_cast<uint32_t>(P.n_prims);
     return closest;
 }
@@ -74,7 +102,33 @@ __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     int i = 0;
-    const int n = P.bvh_nodes;
+    int n = P.bvh_nodes;
+    if (GEN < 2 && P.use_grid) {  // (not for expression programs: few objects, and their kernels are at the register limit)
+        // BVH.getPrimitivesAt through the leaf grid (rm_scene_host.cpp build_point_query_grid): the leaves listed for p's
+        // cell are a superset of the leaves whose box contains p; each is re-tested with the reference's inclusive
+        // binary32 compares, and outside the root box no leaf can contain p.  Crowded cells keep the tree walk.
+        const RmBvhNode root = P.bvh[0];
+        bool walk = false;
+        if (box_contains(root.lo, root.hi, p)) {
+            const int cx = min(max(static_cast<int>((p.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
+            const int cy = min(max(static_cast<int>((p.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
+            const int cz = min(max(static_cast<int>((p.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
+            const uint32_t cell = P.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
+            const int ccnt = static_cast<int>(cell & 0xFFu);
+            if (ccnt == 255) walk = true;
+            else {
+                const uint16_t *lst = P.pq_list + (cell >> 8);
+                for (int e = 0; e < ccnt; ++e) {
+                    const RmBvhNode node = P.bvh[lst[e]];
+                    if (!box_contains(node.lo, node.hi, p)) continue;
+                    const int first = node.leaf >> 8, cnt = node.leaf & 0xFF;
+                    closest = list_min<GEN>(P, P.bvh_prims + first, cnt, p, closest);
+                    found += static_cast<uint32_t>(cnt);
+                }
+            }
+        }
+        if (!walk) n = 0;  // the grid answered: skip the walk
+    }
     while (i < n) {
         const RmBvhNode node = P.bvh[i];
         if (!box_contains(node.lo, node.hi, p)) {
@@ -306,6 +360,38 @@ __device__ double normal_and_store(const RmRenderParams &P, const Ray &ray, doub
     return depth;
 }
 
+// The per-ray hit-leaf list of rm_bvh_list.h in this kernel: BVH.onRayMarchStart walks the tree once and records the
+// leaves the ray hits; every later "next interval" scans that short list instead of walking the whole tree again with a
+// slab test per node (what bvh_next_interval does; it remains for launches without the list).  The list lives in dynamic
+// LDS behind the expression programs' slots (list_lds_offset), RM_V1_LIST_CAP entries of 2 B per lane.
+#define RM_V1_LIST_CAP 16
+__device__ __forceinline__ SceneView v1_view(const RmRenderParams &P) {
+    SceneView S;
+    S.nodes = P.bvh;
+    S.bvh_prims = P.bvh_prims;
+    S.oct = P.oct;
+    S.oct_prims = P.oct_prims;
+    S.spheres = P.spheres;
+    S.radii = P.radii;
+    S.pq_cells = P.pq_cells;
+    S.pq_list = P.pq_list;
+    S.nn_cells = P.nn_cells;
+    S.nn_list = P.nn_list;
+    S.rel = nullptr;
+    S.n_prims = P.n_prims;
+    S.bvh_nodes = P.bvh_nodes;
+    return S;
+}
+__device__ __forceinline__ RayList v1_ray_list(const RmRenderParams &P) {
+    extern __shared__ __align__(16) unsigned char v1_smem[];
+    RayList L;
+    L.cap = RM_V1_LIST_CAP;
+    L.cnt = L.live = L.cur_pos = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    L.col = reinterpret_cast<uint16_t *>(v1_smem + P.v1_list_offset) + (static_cast<size_t>(wave) * RM_V1_LIST_CAP) * 64 + lane;
+    return L;
+}
+
 // SphereTracer.rayMarch (sphereTracer.ts:15-83)
 template <int ACCEL, int GEN>
 __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &count, uint32_t &iters) {
@@ -314,10 +400,17 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
     bool haveCur = false;
     RayInv ri;
     OctInv oinv;
+    RayList L;
+    const bool lists = ACCEL == 2 && GEN < 2 && P.v1_list_offset >= 0;  // expression programs: a handful of objects, nothing to gain
     if (ACCEL == 1) oinv = make_oct_inv(ray);
     if (ACCEL == 2) {
         ri = make_ray_inv(ray);
-        haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);  // onRayMarchStart
+        if (lists) {
+            L = v1_ray_list(P);
+            haveCur = bvh_prologue<false>(v1_view(P), ray, ri, L, cur);  // onRayMarchStart
+        } else {
+            haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);
+        }
         if (!haveCur) return RM_MAX_DIST;                                // bvh.ts:190-192
     }
     for (int i = 0; i < RM_MAX_STEPS; ++i) {
@@ -333,7 +426,8 @@ __device__ double ray_march(const RmRenderParams &P, const Ray &ray, uint32_t &c
             if (t < cur.tEnter) skip = cur.tEnter - t;
             else if (t > cur.tExit) {
                 const Interval prev = cur;
-                haveCur = bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);  // idx++
+                haveCur = lists ? bvh_next<false>(v1_view(P), ray, ri, L, prev.tEnter, prev.ord, cur)
+                                : bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);  // idx++
                 if (!haveCur) return RM_MAX_DIST;
                 if (cur.tEnter > t) skip = cur.tEnter - t;
             }
@@ -383,10 +477,17 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     bool haveCur = false;
     RayInv ri;
     OctInv oinv;
+    RayList L;
+    const bool lists = ACCEL == 2 && GEN < 2 && P.v1_list_offset >= 0;  // expression programs: a handful of objects, nothing to gain
     if (ACCEL == 1) oinv = make_oct_inv(ray);
     if (ACCEL == 2) {
         ri = make_ray_inv(ray);
-        haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);
+        if (lists) {
+            L = v1_ray_list(P);
+            haveCur = bvh_prologue<false>(v1_view(P), ray, ri, L, cur);
+        } else {
+            haveCur = bvh_next_interval(P, ray, ri, -__builtin_inf(), -1, cur);
+        }
         if (!haveCur) return RM_MAX_DIST;
     }
     for (int i = 0; i < max_steps; ++i) {
@@ -398,7 +499,8 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
             if (t < cur.tEnter) skip = cur.tEnter - t;
             else if (t > cur.tExit) {
                 const Interval prev = cur;
-                haveCur = bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);
+                haveCur = lists ? bvh_next<false>(v1_view(P), ray, ri, L, prev.tEnter, prev.ord, cur)
+                                : bvh_next_interval(P, ray, ri, prev.tEnter, prev.ord, cur);
                 if (!haveCur) return RM_MAX_DIST;
                 if (cur.tEnter > t) skip = cur.tEnter - t;
             }
@@ -740,10 +842,16 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
     const int tiles_y = (rows + 4 * th - 1) / (4 * th);
     const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
     // expression programs keep their position slots and pending values in LDS (rm_program.h)
-    const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+    size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+    RmRenderParams pl = p;
+    pl.v1_list_offset = -1;
+    if (p.accel == 2 && p.v1_lists && p.general < 2 && p.bvh_nodes < 65536 && shmem + 4 * RM_V1_LIST_CAP * 128 <= 64 * 1024) {
+        pl.v1_list_offset = static_cast<int32_t>((shmem + 15) & ~static_cast<size_t>(15));  // per-ray hit-leaf lists behind the program slots
+        shmem = static_cast<size_t>(pl.v1_list_offset) + 4 * RM_V1_LIST_CAP * 128;
+    }
 #define RM_V1(A, O, G)                                                                       \
     {                                                                                        \
-        hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, shmem, stream, p);         \
+        hipLaunchKernelGGL((render_kernel<A, O, G>), grid, block, shmem, stream, pl);         \
         if (kernel_name) *kernel_name = "render_kernel<" #A ", " #O ", " #G ">" RM_LEN_TAG;  \
     }
 #define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G) else if (p.accel == 1) RM_V1(1, O, G) else RM_V1(0, O, G) }

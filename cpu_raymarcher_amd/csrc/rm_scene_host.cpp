@@ -239,6 +239,7 @@ void build_point_query_grid(HostScene &s) {
     // real-number bounds and the reference's rounded arithmetic (~1e-15) by many orders.
     // The candidate grid is finer than the leaf grid (cell diagonal << sphere spacing keeps the lists at a
     // handful of spheres): up to 48 cells per axis, bounded by the host work cells * n.
+    if (s.general || s.program) return;  // nearest-candidate lists need exact sphere distances (general scenes keep bounding spheres here)
     const size_t n = s.spheres.size();
     if (n == 0 || n > 2048) return;  // used for scenes of <= 512 spheres by default (rm_api.cpp), on request up to 2048
     int ng = 48;
@@ -466,7 +467,7 @@ static bool build_accel(HostScene &s, int n, std::string &err) {
         if (!b.ok) return false;
         std::memcpy(s.root_min, root.lo, sizeof root.lo);
         std::memcpy(s.root_max, root.hi, sizeof root.hi);
-        if (!s.general) build_point_query_grid(s);
+        build_point_query_grid(s);  // the leaf grid only knows leaf boxes: it serves every primitive representation
     } else if (s.accel == 1) {
         Box root;  // scene.ts:81-85
         for (int k = 0; k < 3; ++k) {
@@ -786,7 +787,31 @@ bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, 
             s.prim_lo[3 * i + k] = to_f32(double(l2w.m[12 + k]) - pad);
             s.prim_hi[3 * i + k] = to_f32(double(l2w.m[12 + k]) + pad);
         }
+        // Bounding sphere for the all-primitive fallback's candidate filter (rm_kernels.hip, all_prims_distance): for a RIGID
+        // world->local matrix (orthonormal 3x3, bottom row 0 0 0 1) Primitive.sdf is a true distance in world space and the
+        // primitive lies inside the ball (centre c = the point mapped to the local origin, radius R = |halfSize| for a box,
+        // major + minor for a torus, |r| for a sphere), hence  |p - c| - R <= sdf(p) <= |p - c| + R  for every p.  Anything
+        // else (scale, shear, projective rows) switches the filter off for the whole scene.
+        {
+            bool rigid = ok && (q.type & 0x100);
+            const float *w = q.m;
+            for (int a = 0; rigid && a < 3; ++a)
+                for (int b = a; b < 3; ++b) {
+                    const double dot = double(w[4 * a]) * w[4 * b] + double(w[4 * a + 1]) * w[4 * b + 1] + double(w[4 * a + 2]) * w[4 * b + 2];
+                    if (std::fabs(dot - (a == b ? 1.0 : 0.0)) > 1e-6) rigid = false;  // 1e-6 x |p - c| stays inside the filter's 4e-6 margin
+                }
+            if (!rigid) s.prim_filter_ok = false;
+            const double cabs = std::fabs(double(l2w.m[12])) + std::fabs(double(l2w.m[13])) + std::fabs(double(l2w.m[14]));
+            RmSphere bs;
+            bs.cx = l2w.m[12];
+            bs.cy = l2w.m[13];
+            bs.cz = l2w.m[14];
+            // slack: the inverse's rounding (1e-6 relative on c), the 1e-6 orthonormality tolerance over the radius
+            bs.rf = std::nextafter(static_cast<float>(std::fabs(local_radius) * (1.0 + 3e-5) + 1e-5 * (1.0 + cabs)), INFINITY);
+            s.spheres.push_back(bs);
+        }
     }
+    if (n == 0) s.prim_filter_ok = false;
     return build_accel(s, n, err);
 }
 

@@ -71,6 +71,7 @@ struct HostScene {
     // BVH's nearest-candidate grid, but taken over the leaf's own list, which is what Scene.getDistance evaluates.
     std::vector<uint32_t> oct_sub_hdr;
     std::vector<uint8_t> oct_sub_list;
+    bool prim_filter_ok = true;  // general scenes: every primitive's transform is rigid, `spheres` holds their bounding spheres
     int oct_leaves = 0, oct_empty = 0, oct_max_leaf = 0;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 };

@@ -136,6 +136,9 @@ struct RmRenderParams {
     const uint8_t *lpt_cost_prev;
     uint16_t *lpt_perm_out;  // what the sort kernel of this launch writes (== lpt_perm)
     int32_t lpt_stride, lpt_pad;
+    int32_t v1_lists;          // v1 BVH: per-ray hit-leaf lists in LDS (option `v1_lists`), placed at v1_list_offset by the launcher
+    int32_t v1_list_offset;
+    int32_t prim_filter;       // general primitives (RmPrim): `spheres` holds a bounding sphere per primitive (rigid transforms only)
     int32_t n0_batch;          // v2 BVH: lanes waiting for getNormal that trigger the normal round while others still march (64: never)
     const int32_t *stripe_ids; // non-null (with stripe_rows > 0): the launch renders the stripes stripe_ids[0 .. ) in this
                                // order (increasing), packed; any deal of stripes to parts, e.g. a weighted one

@@ -259,8 +259,7 @@ __device__ double oct_node_distance(const RmRenderParams &P, int node, const Vec
             const uint8_t *sub = nullptr;
             int n_sub = 0;
             if (P.oct_sub_hdr && nd.sub_first >= 0) {  // crowded leaf: the candidates of p's sub-cell
-                const float S = static_cast<float>(RM_OCT_SUB);
-                const float ix = S / (nd.hi[0] - nd.lo[0]), iy = S / (nd.hi[1] - nd.lo[1]), iz = S / (nd.hi[2] - nd.lo[2]);
+                const float ix = nd.center[0], iy = nd.center[1], iz = nd.center[2];  // RM_OCT_SUB / (hi - lo), from the host
                 const int sx = min(max(static_cast<int>((p.x - nd.lo[0]) * ix), 0), RM_OCT_SUB - 1);
                 const int sy = min(max(static_cast<int>((p.y - nd.lo[1]) * iy), 0), RM_OCT_SUB - 1);
                 const int sz = min(max(static_cast<int>((p.z - nd.lo[2]) * iz), 0), RM_OCT_SUB - 1);

@@ -508,6 +508,9 @@ static bool build_accel(HostScene &s, int n, std::string &err) {
                 if (nd.first_child >= 0 || n <= 8 || n > 255) continue;
                 if (s.oct_sub_list.size() + size_t(RM_OCT_SUB) * RM_OCT_SUB * RM_OCT_SUB * size_t(n) >= (1u << 24)) break;
                 nd.sub_first = static_cast<int32_t>(s.oct_sub_hdr.size());
+                // a leaf has no split point: `center` carries the sub-cells per unit length instead, so the kernel indexes a
+                // sub-cell with three multiplications and no division (binary32 quotient, as the kernel used to form it)
+                for (int k = 0; k < 3; ++k) nd.center[k] = static_cast<float>(RM_OCT_SUB) / (nd.hi[k] - nd.lo[k]);
                 std::vector<double> lb(n);
                 for (int cz = 0; cz < RM_OCT_SUB; ++cz)
                     for (int cy = 0; cy < RM_OCT_SUB; ++cy)

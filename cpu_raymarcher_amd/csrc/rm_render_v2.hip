@@ -653,22 +653,22 @@ __device__ bool bvh_prologue_cull(const SceneView &S, const RmRenderParams &C, c
 
 // ---- the kernel ------------------------------------------------------------------------------
 
-// Where every staged table lives in LDS: a pure function of the launch parameters (counts), so that any section of
-// the wave loop can rebuild its SceneView from freshly loaded parameters (cold_params) with a handful of scalar
-// instructions, instead of keeping a dozen table addresses and scene constants in SGPRs across the whole loop -- where
+// Where every staged table lives in LDS: a pure function of the launch parameters (counts), evaluated once by the launcher
+// and handed over in RmRenderParams::lds_off, so that any section of the wave loop can rebuild its SceneView from freshly
+// loaded parameters (cold_params) with one scalar load, instead of keeping a dozen table addresses and scene constants in SGPRs across the whole loop -- where
 // they do not fit: the first build spilled 130 SGPRs to VGPR lanes and a tenth of the wave loop's straight-line
 // instructions were v_readlane reloads (4.7 issue cycles each, profiles/r02/valu_issue_costs.json).
 struct LdsLayout {
     uint32_t nodes, prims, cells, list, oct, oct_prims, spheres, radii, rel, end;
 };
-template <int ACCEL, bool LDS, bool REL>
-__device__ __forceinline__ LdsLayout lds_layout(const RmRenderParams &C) {
+// the one definition of the layout, used by the launcher (which writes it into RmRenderParams::lds_off)
+inline LdsLayout lds_layout_host(const RmRenderParams &C, int accel, bool lds, bool rel) {
     auto up = [](uint32_t v) { return (v + 15u) & ~15u; };
     auto words = [](uint32_t count, uint32_t size) { return ((count * size + 3u) / 4u) * 4u; };
     LdsLayout o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t off = 0;
-    if (LDS) {
-        if (ACCEL == 2) {
+    if (lds) {
+        if (accel == 2) {
             o.nodes = off = up(off);
             off += words(static_cast<uint32_t>(C.bvh_nodes), sizeof(RmBvhNode));
             o.prims = off = up(off);
@@ -677,7 +677,7 @@ __device__ __forceinline__ LdsLayout lds_layout(const RmRenderParams &C) {
             off += words(static_cast<uint32_t>(C.pq_cell_count), 4);
             o.list = off = up(off);
             off += words(static_cast<uint32_t>(C.pq_list_count), 2);
-        } else if (ACCEL == 1) {
+        } else if (accel == 1) {
             o.oct = off = up(off);
             off += words(static_cast<uint32_t>(C.oct_nodes), sizeof(RmOctNode));
             o.oct_prims = off = up(off);
@@ -688,12 +688,27 @@ __device__ __forceinline__ LdsLayout lds_layout(const RmRenderParams &C) {
         o.radii = off = up(off);
         off += words(static_cast<uint32_t>(C.n_prims), 8);
         off = up(off);
-        if (REL) {
+        if (rel) {
             o.rel = off;
             off += static_cast<uint32_t>(C.bvh_nodes) * 48u;
         }
     }
     o.end = off;
+    return o;
+}
+template <int ACCEL, bool LDS, bool REL>
+__device__ __forceinline__ LdsLayout lds_layout(const RmRenderParams &C) {
+    LdsLayout o;
+    o.nodes = C.lds_off[0];
+    o.prims = C.lds_off[1];
+    o.cells = C.lds_off[2];
+    o.list = C.lds_off[3];
+    o.oct = C.lds_off[4];
+    o.oct_prims = C.lds_off[5];
+    o.spheres = C.lds_off[6];
+    o.radii = C.lds_off[7];
+    o.rel = C.lds_off[8];
+    o.end = C.lds_off[9];
     return o;
 }
 template <int ACCEL, bool LDS, bool REL>
@@ -811,7 +826,14 @@ template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 // (the REL instantiations keep six more doubles' worth of addressing live in the slab tests: at five waves they spill
 // VGPRs to scratch -- and gave wrong pixels with it, non-deterministically, in the build that first did -- so they are
 // compiled for four waves per SIMD; the launcher only picks them where the LDS budget leaves room, i.e. small scenes)
-__global__ __launch_bounds__(256, REL ? 4 : 5) void render_kernel_v2(const RmRenderParams P) {
+// (likewise the vec3.length = sqrt(x*x + y*y + z*z) build: the compiler's full-range IEEE sqrt needs a register more than the
+// budget of five waves has)
+#ifdef RM_LENGTH_SQRT
+#define RM_V2_WAVES(REL) 4
+#else
+#define RM_V2_WAVES(REL) ((REL) ? 4 : 5)
+#endif
+__global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -1318,6 +1340,12 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
         }
     }
     const size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
+    {
+        const LdsLayout lay = lds_layout_host(p, p.accel, lds, rel && p.accel == 2);
+        const uint32_t v[10] = {lay.nodes, lay.prims, lay.cells, lay.list, lay.oct, lay.oct_prims, lay.spheres, lay.radii, lay.rel, lay.end};
+        for (int k = 0; k < 10; ++k) p.lds_off[k] = v[k];
+        if (lay.end + list_bytes > shmem) return hipErrorInvalidValue;  // the layout and the allocation come from two formulas: they must agree
+    }
     resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) * static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
     blocks = needed < resident ? (needed ? needed : 1u) : resident;
     // static share: three quarters of the shortest queue, in whole rounds over all waves

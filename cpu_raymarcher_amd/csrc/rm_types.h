@@ -138,6 +138,8 @@ struct RmRenderParams {
     int32_t lpt_stride, lpt_pad;
     int32_t v1_lists;          // v1 BVH: per-ray hit-leaf lists in LDS (option `v1_lists`), placed at v1_list_offset by the launcher
     int32_t v1_list_offset;
+    uint32_t lds_off[10];      // v2: byte offsets of the staged tables in LDS (nodes, prims, cells, list, oct, oct_prims, spheres,
+                               // radii, rel, end), computed by the launcher: a section rebuilds its view from one scalar load
     int32_t prim_filter;       // general primitives (RmPrim): `spheres` holds a bounding sphere per primitive (rigid transforms only)
     int32_t n0_batch;          // v2 BVH: lanes waiting for getNormal that trigger the normal round while others still march (64: never)
     const int32_t *stripe_ids; // non-null (with stripe_rows > 0): the launch renders the stripes stripe_ids[0 .. ) in this

@@ -26,6 +26,7 @@ def main():
     dev = torch.device("cuda:0")
     ctx = R.Context(0)
     ctx.set_option("blocks_per_cu", 1)  # what bench.py uses with frames in flight
+    ctx.set_option("lpt", 0)            # likewise: overlapping frames hide the tail the longest-first order is for
     if wl == "C5":
         from cpu_raymarcher_amd.synthetic import synthetic_spheres
         scene = R.Scene("Octree", ctx=ctx)

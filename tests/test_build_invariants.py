@@ -1,0 +1,48 @@
+"""Build-time invariants of the gfx950 kernels that a parity test cannot see until it is too late (CPU only: hipcc
+cross-compiles).  Round 2 found one the hard way: the v2 REL instantiations spilled 21 VGPRs to scratch at five waves per
+SIMD and rendered wrong pixels, non-deterministically.  No v2 render kernel may spill a VGPR, and the headline
+instantiation must keep its five waves per SIMD."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cpu_raymarcher_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="hipcc / c++filt not present")
+
+
+def resource_usage(extra=()):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, "rm_render_v2.hip"), *extra],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
+    rows, cur = [], None
+    for line in out.split("\n"):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            rows.append(cur)
+            continue
+        for key in ("VGPRs Spill", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "VGPRs"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and cur is not None and key not in cur:
+                cur[key] = int(m.group(1))
+    names = subprocess.check_output(["c++filt"] + [r["name"] for r in rows]).decode().split("\n")
+    return {n.replace("(anonymous namespace)::", ""): r for n, r in zip(names, rows)}
+
+
+@pytest.mark.parametrize("extra", [(), ("-DRM_LENGTH_SQRT",)])
+def test_v2_render_kernels_do_not_spill_vgprs(extra):
+    usage = resource_usage(extra)
+    kernels = {n: r for n, r in usage.items() if "render_kernel_v2<" in n}
+    assert len(kernels) >= 9, sorted(usage)
+    for name, r in kernels.items():
+        assert r["VGPRs Spill"] == 0, (name, r)
+    headline = [r for n, r in kernels.items() if n.startswith("void render_kernel_v2<2, true, true, false>")]
+    assert headline and headline[0]["ScratchSize [bytes/lane]"] == 0, headline
+    # five waves per SIMD in the default build; the sqrt build is compiled for four (full-range IEEE sqrt needs the registers)
+    assert headline[0]["Occupancy [waves/SIMD]"] >= (4 if extra else 5), headline

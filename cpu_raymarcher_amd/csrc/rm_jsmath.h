@@ -8,6 +8,17 @@
 // root, the word-level tests done on the bit pattern.  `rm_selftest_jsmath` evaluates them on the
 // GPU for the parity tests.  Argument reduction is complete (medium path up to 2^19*pi/2, Payne-Hanek
 // beyond; the latter is an out-of-line function with its tables in scratch, reached only by huge arguments).
+//
+// The algorithms and the polynomial / table constants restated below are those of fdlibm 5.3, which carries this notice:
+//
+//   ====================================================
+//   Copyright (C) 1993-2004 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <stdint.h>
 

@@ -369,6 +369,17 @@ function octSkip(O, o, d, t) { // octree.ts:252-278 + 195-220
 // ---------------------------------------------------------------- scene distance
 // Math.pow is the one transcendental whose node-12 (V8 7.8) value is not the fdlibm one that
 // current V8 computes (ieee754::legacy::pow); e_pow.c is therefore restated here as well.
+//
+// The algorithms and the polynomial / table constants restated below are those of fdlibm 5.3, which carries this notice:
+//
+//   ====================================================
+//   Copyright (C) 1993-2004 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 const _f64 = new Float64Array(1), _u32 = new Uint32Array(_f64.buffer);
 function hiWord(x) { _f64[0] = x; return _u32[1] | 0; }
 function loWord(x) { _f64[0] = x; return _u32[0] >>> 0; }

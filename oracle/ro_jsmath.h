@@ -11,6 +11,17 @@
  * node binary in the build container (tests/test_oracle_kat.py::test_jsmath_equals_node).
  * Argument reduction is complete: the "medium" path of e_rem_pio2.c up to 2^19*pi/2 and the
  * Payne-Hanek path of k_rem_pio2.c beyond.
+ *
+ * The algorithms and the polynomial / table constants restated below are those of fdlibm 5.3, which carries this notice:
+ *
+ *   ====================================================
+ *   Copyright (C) 1993-2004 by Sun Microsystems, Inc. All rights reserved.
+ *
+ *   Developed at SunSoft, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this
+ *   software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
  */
 #ifndef RO_JSMATH_H
 #define RO_JSMATH_H

@@ -93,6 +93,7 @@ struct rm_ctx {
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
     int64_t opt_v1_lists = 1;  // v1 BVH kernels: per-ray hit-leaf lists instead of one tree walk per interval advance
+    int64_t opt_oct_lean = 1;  // octree, sphere scenes, sphere tracer: render_kernel_oct (rm_kernels.hip) instead of render_kernel<1, false, 0>
     int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's costs (shortens the tail of a frame that runs alone)
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
     // permutation and records its own costs); geometry changes restart the feedback
@@ -483,6 +484,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
     p.n0_batch = static_cast<int32_t>(ctx->opt_n0_batch);
     p.v1_lists = static_cast<int32_t>(ctx->opt_v1_lists);
+    p.oct_lean = static_cast<int32_t>(ctx->opt_oct_lean);  // the camera is finite (fill_params), so every march point is
     p.v1_list_offset = -1;
     p.prim_filter = (ctx->opt_filter && ctx->host.general && !ctx->host.program && ctx->host.prim_filter_ok &&
                      ctx->host.spheres.size() == ctx->host.prims.size()) ? 1 : 0;
@@ -1213,6 +1215,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_v1_lists = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "oct_lean")) {
+        ctx->opt_oct_lean = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "lpt")) {
         ctx->opt_lpt = value ? 1 : 0;
         return RM_OK;
@@ -1260,6 +1266,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "n0_batch")) *value = ctx->opt_n0_batch;
     else if (!std::strcmp(key, "lpt")) *value = ctx->opt_lpt;
     else if (!std::strcmp(key, "v1_lists")) *value = ctx->opt_v1_lists;
+    else if (!std::strcmp(key, "oct_lean")) *value = ctx->opt_oct_lean;
     else return RM_E_INVALID;
     return RM_OK;
 }

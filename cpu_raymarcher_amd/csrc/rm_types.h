@@ -149,7 +149,8 @@ struct RmRenderParams {
     const uint32_t *pq_cells;
     const uint16_t *pq_list;
     const uint16_t *bvh_leaves;  // v2 bundle cull: node indices of the non-empty leaves, increasing; bvh_leaf_count entries (0: off)
-    int32_t bvh_leaf_count, reserved4;
+    int32_t bvh_leaf_count;
+    int32_t oct_lean;  // v1, octree, sphere scenes with the cell table: the lean sphere-tracer kernel (render_kernel_oct; option `oct_lean`)
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
     int32_t nn_cell_count, nn_list_count, use_nn;

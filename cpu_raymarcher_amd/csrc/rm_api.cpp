@@ -72,6 +72,7 @@ struct rm_ctx {
     float light[3] = {0, 0, 0};
 
     int64_t opt_tile_w = 16;
+    bool tile_w_set = false;  // rm_set_option("tile_w") was called: the value then holds for every kernel (else v1 kernels use 8 x 8 wave tiles)
     int64_t opt_filter = 1;
     int64_t opt_lds = 1;
     int64_t opt_kernel = 0;  // 0 = auto: v2 for BVH / no acceleration, v1 for the octree (measured faster)
@@ -93,6 +94,7 @@ struct rm_ctx {
     int64_t opt_sub = 1;   // crowded octree leaves scan their sub-cell candidate lists
     int64_t opt_hw_xcd = 1;
     int64_t opt_v1_lists = 1;  // v1 BVH kernels: per-ray hit-leaf lists instead of one tree walk per interval advance
+    int64_t opt_v1_block = 64;  // v1 kernels: threads per workgroup (one wave: wave slots refill one by one)
     int64_t opt_oct_lean = 1;  // octree, sphere scenes, sphere tracer: render_kernel_oct (rm_kernels.hip) instead of render_kernel<1, false, 0>
     int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's costs (shortens the tail of a frame that runs alone)
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
@@ -104,6 +106,22 @@ struct rm_ctx {
     unsigned int lpt_launch = 0;
     long long lpt_geometry = -1;
     hipEvent_t lpt_done[16] = {};  // recorded after the launch that owns the slot: a slot is reused only once that launch is over
+    // render_kernel_oct: the octree relative to a camera position (RmOctFrameNode), one table per position in a ring.  A table is
+    // shared by every launch with that position (frames in flight with one camera build it once) and rewritten only when the
+    // ring comes round, after every launch that read it has finished (one event per stream that used it).
+    struct OctFrameSlot {
+        double origin[3] = {0, 0, 0};
+        unsigned long long gen = 0;
+        bool valid = false;
+        RmOctFrameNode *dev = nullptr;
+        size_t nodes = 0;
+        std::vector<std::pair<hipStream_t, hipEvent_t>> users;
+    };
+    static constexpr int kOctFrameSlots = 32;
+    OctFrameSlot oct_frames[kOctFrameSlots];
+    unsigned oct_frame_next = 0;
+    int oct_frame_cur = -1;
+    unsigned long long scene_gen = 0;  // bumped by every upload_scene
     int64_t opt_n0_batch = 64;  // v2 BVH: see RmRenderParams::n0_batch
     int64_t opt_length = 0;  // vec3.length: 0 Math.hypot (gl-matrix 3.0 - 3.4.3), 1 Math.sqrt(x*x + y*y + z*z)
     const char *last_kernel = "";
@@ -136,6 +154,40 @@ int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
 // the kernels exist twice: vec3.length = Math.hypot, and = sqrt(x*x + y*y + z*z) (rm_kernels.h, option `length`)
 hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
+    rm_ctx::OctFrameSlot *oct_slot = nullptr;
+    if (p.accel == 1 && p.oct_lean && !p.general && p.algorithm == 0 && p.oct_lut && p.oct_recs && p.filter) {
+        const size_t n = static_cast<size_t>(p.oct_nodes);
+        auto matches = [&](const rm_ctx::OctFrameSlot &sl) {
+            return sl.valid && sl.gen == ctx->scene_gen && sl.origin[0] == p.origin_d[0] && sl.origin[1] == p.origin_d[1] && sl.origin[2] == p.origin_d[2];
+        };
+        if (ctx->oct_frame_cur >= 0 && matches(ctx->oct_frames[ctx->oct_frame_cur])) oct_slot = &ctx->oct_frames[ctx->oct_frame_cur];
+        for (int k = 0; !oct_slot && k < rm_ctx::kOctFrameSlots; ++k)
+            if (matches(ctx->oct_frames[k])) {
+                oct_slot = &ctx->oct_frames[k];
+                ctx->oct_frame_cur = k;
+            }
+        if (!oct_slot) {  // a new camera position: the oldest table is rewritten once its readers are done
+            const int k = static_cast<int>(ctx->oct_frame_next++ % rm_ctx::kOctFrameSlots);
+            rm_ctx::OctFrameSlot &sl = ctx->oct_frames[k];
+            for (auto &u : sl.users) (void)hipEventSynchronize(u.second);
+            sl.valid = false;
+            if (sl.nodes < n) {
+                (void)hipFree(sl.dev);
+                sl.dev = nullptr;
+                sl.nodes = 0;
+                if (hipMalloc(reinterpret_cast<void **>(&sl.dev), n * sizeof(RmOctFrameNode)) == hipSuccess) sl.nodes = n;
+                else (void)hipGetLastError();
+            }
+            if (sl.dev && rm_launch_oct_frame_table(p.oct, p.oct_nodes, p.origin_d, sl.dev, stream) == hipSuccess) {
+                for (int a = 0; a < 3; ++a) sl.origin[a] = p.origin_d[a];
+                sl.gen = ctx->scene_gen;
+                sl.valid = true;
+                oct_slot = &sl;
+                ctx->oct_frame_cur = k;
+            }
+        }
+        p.oct_frame = oct_slot ? oct_slot->dev : nullptr;  // null: the launcher takes render_kernel<1, false, 0>
+    }
     if (ctx->opt_lpt && p.variant == 2 && p.algorithm == 0) {  // longest-first item order (rm_render_v2.hip, lpt_sort_kernel)
         const size_t per_slot = static_cast<size_t>(8) * rm_ctx::kLptStride;
         if (!ctx->d_lpt_cost) {
@@ -162,6 +214,20 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
         }
     }
     const hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+    if (oct_slot) {  // this stream now reads the table: whoever rewrites it waits for this launch
+        hipEvent_t *ev = nullptr;
+        for (auto &u : oct_slot->users)
+            if (u.first == stream) ev = &u.second;
+        if (!ev) {
+            hipEvent_t fresh = nullptr;
+            if (hipEventCreateWithFlags(&fresh, hipEventDisableTiming) == hipSuccess) {
+                oct_slot->users.emplace_back(stream, fresh);
+                ev = &oct_slot->users.back().second;
+            }
+        }
+        if (ev) (void)hipEventRecord(*ev, stream);
+        else (void)hipStreamSynchronize(stream);  // no event to be had: the table must not outlive its reader unseen
+    }
     if (e == hipSuccess && p.lpt_perm_out) {
         const unsigned slot = (ctx->lpt_launch + rm_ctx::kLptSlots - 1) % rm_ctx::kLptSlots;
         if (!ctx->lpt_done[slot]) (void)hipEventCreateWithFlags(&ctx->lpt_done[slot], hipEventDisableTiming);
@@ -235,6 +301,7 @@ int upload_scene(rm_ctx *ctx) {
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, hipDeviceSynchronize());  // nothing may still read the old tables
     free_device_scene(ctx);
+    ctx->scene_gen++;  // the octree frame tables of the old scene are stale
     int rc;
     if ((rc = upload_vec(ctx, ctx->host.spheres, &ctx->dev.spheres))) return rc;
     if ((rc = upload_vec(ctx, ctx->host.radii, &ctx->dev.radii))) return rc;
@@ -450,6 +517,9 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     if (p.variant == 0) p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 24) ? 1 : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
     if (ctx->host.general) p.variant = 1;                    // so do boxes, tori and rotated primitives
+    // v1: square 8 x 8 wave tiles keep a wave's rays in the same leaves / intervals (N3-mixed 2.31 -> 2.07 ms together with
+    // one-wave workgroups, option `v1_block`)
+    if (p.variant == 1 && !ctx->tile_w_set) p.tile_w = 8;
     p.list_cap = static_cast<int32_t>(ctx->opt_list_cap);
     p.coop = static_cast<int32_t>(ctx->opt_coop);
     p.bvh_prim_count = static_cast<int32_t>(ctx->host.bvh_prims.size());
@@ -484,6 +554,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.rel_boxes = static_cast<int32_t>(ctx->opt_rel);
     p.n0_batch = static_cast<int32_t>(ctx->opt_n0_batch);
     p.v1_lists = static_cast<int32_t>(ctx->opt_v1_lists);
+    p.v1_block = static_cast<int32_t>(ctx->opt_v1_block);
     p.oct_lean = static_cast<int32_t>(ctx->opt_oct_lean);  // the camera is finite (fill_params), so every march point is
     p.v1_list_offset = -1;
     p.prim_filter = (ctx->opt_filter && ctx->host.general && !ctx->host.program && ctx->host.prim_filter_ok &&
@@ -573,6 +644,10 @@ void rm_destroy(rm_ctx *ctx) {
         (void)hipFree(ctx->d_lpt_perm);
         for (hipEvent_t ev : ctx->lpt_done)
             if (ev) (void)hipEventDestroy(ev);
+        for (auto &sl : ctx->oct_frames) {
+            (void)hipFree(sl.dev);
+            for (auto &u : sl.users) (void)hipEventDestroy(u.second);
+        }
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1125,6 +1200,7 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     if (!std::strcmp(key, "tile_w")) {
         if (value != 8 && value != 16 && value != 32 && value != 64) return fail(ctx, RM_E_INVALID, "tile_w must be 8, 16, 32 or 64");
         ctx->opt_tile_w = value;
+        ctx->tile_w_set = true;
         return RM_OK;
     }
     if (!std::strcmp(key, "filter")) {
@@ -1215,6 +1291,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_v1_lists = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "v1_block")) {
+        if (value != 64 && value != 128 && value != 256) return fail(ctx, RM_E_INVALID, "v1_block must be 64, 128 or 256");
+        ctx->opt_v1_block = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "oct_lean")) {
         ctx->opt_oct_lean = value ? 1 : 0;
         return RM_OK;
@@ -1267,6 +1348,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "lpt")) *value = ctx->opt_lpt;
     else if (!std::strcmp(key, "v1_lists")) *value = ctx->opt_v1_lists;
     else if (!std::strcmp(key, "oct_lean")) *value = ctx->opt_oct_lean;
+    else if (!std::strcmp(key, "v1_block")) *value = ctx->opt_v1_block;
     else return RM_E_INVALID;
     return RM_OK;
 }

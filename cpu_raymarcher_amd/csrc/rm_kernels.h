@@ -33,6 +33,9 @@ hipError_t rm_launch_render_sqrt(const RmRenderParams &p, hipStream_t stream, co
 hipError_t rm_launch_render_v2(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
 hipError_t rm_launch_render_v2_sqrt(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
 
+// the octree's node boxes relative to one camera position, for render_kernel_oct (rm_kernels.hip)
+hipError_t rm_launch_oct_frame_table(const RmOctNode *nodes, int n, const double origin[3], RmOctFrameNode *out, hipStream_t stream);
+
 // ShadingModel.shade over n = width * height pixels.
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
                            const uint16_t *sdf, const uint16_t *iters, uint8_t *rgba,

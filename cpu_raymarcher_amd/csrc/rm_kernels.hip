@@ -626,6 +626,9 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
 //    binary32 (exact either way) and without branches.
 //  * every load is base (SGPR pair) + 32-bit byte offset, and everything a step can need from the node record is
 //    requested in ONE batch right after the cell table's answer.
+//  * (face - origin) is the same binary64 difference for every ray of a frame: oct_frame_table_kernel forms it once per
+//    node and camera position (RmOctFrameNode; rm_api.cpp keeps the tables of the last few camera positions), and the
+//    march step multiplies it by the ray's 1 / d.  minDistance * 0.99 (octree.ts:282) sits beside it.
 //  * getNormal's four samples are four more trips of the SAME loop (a phase per ray, as in the v2 kernel): one copy of
 //    the distance code, and a ray that has finished marching shares its evaluations with neighbours that still march.
 // Leaf records, sub-cell candidate lists, filter margins, shading and counters are those of render_kernel<1, ...>,
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     // 1 / direction (octree.ts:200) and, per axis, the byte offset inside RmOctNode of the face the ray leaves through
     // (lo: 0, hi: 16, + 4 per axis): `if (invDir < 0) swap(t0, t1)` (octree.ts:204-208) decided once per ray
     const double inv0 = 1.0 / static_cast<double>(ray.d.x), inv1 = 1.0 / static_cast<double>(ray.d.y), inv2 = 1.0 / static_cast<double>(ray.d.z);
-    const uint32_t far0 = inv0 < 0.0 ? 0u : 16u, far1 = inv1 < 0.0 ? 4u : 20u, far2 = inv2 < 0.0 ? 8u : 24u;
+    const uint32_t far0 = inv0 < 0.0 ? 0u : 32u, far1 = inv1 < 0.0 ? 8u : 40u, far2 = inv2 < 0.0 ? 16u : 48u;  // into RmOctFrameNode
     // tEnter needs no evaluation when tExit is clearly ahead.  The march point p = fl32(o + d t) lies inside the leaf's box
     // (findNode), so on every axis the ray's real entry parameter is at most t + eps / |d_a| with eps < 6e-7 (the binary32
     // rounding of a coordinate of magnitude <= 10; the binary64 roundings are nine orders smaller), and the computed tMin of
@@ -696,6 +699,7 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     double t = 0.0, d0 = 0.0;
     float nx = 0.f, ny = 0.f, nz = 0.f;
     const void *const nodes = P.oct;
+    const void *const frame = P.oct_frame;
     // One structured body per trip (no `continue` / `break`: each of them costs a loop level of mask bookkeeping in the
     // compiled code): a trip either skips, or evaluates one distance and consumes it according to the ray's phase.
     while (phase != PH_DONE) {
@@ -722,27 +726,23 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
                 const uint32_t node = static_cast<uint32_t>(ld_off<int32_t>(P.oct_lut, cell * 4u));
                 __builtin_assume(node < (1u << 24));
                 const uint32_t nb = node * 64u;
-                // one batch: faces, minDistance / primCount / isEmpty, and what a leaf evaluation reads
-                const float ff0 = ld_off<float>(nodes, nb + far0), ff1 = ld_off<float>(nodes, nb + far1), ff2 = ld_off<float>(nodes, nb + far2);
-                const float fn0 = ld_off<float>(nodes, nb + (far0 ^ 16u)), fn1 = ld_off<float>(nodes, nb + (far1 ^ 16u)),
-                            fn2 = ld_off<float>(nodes, nb + (far2 ^ 16u));
-                const double min_distance = ld_off<double>(nodes, nb + 32u);
-                const int2 pc_ie = ld_off<int2>(nodes, nb + 40u);  // prim_count, is_empty
+                // one batch: the far faces and the skip cap of the frame's table, primCount / isEmpty, and what a leaf evaluation reads
+                const double ff0 = ld_off<double>(frame, nb + far0), ff1 = ld_off<double>(frame, nb + far1), ff2 = ld_off<double>(frame, nb + far2);
+                const double cap = ld_off<double>(frame, nb + 24u);  // minDistance * 0.99
+                const int2 pc_ie = ld_off<int2>(nodes, nb + 40u);    // prim_count, is_empty
                 const int prim_first = ld_off<int32_t>(nodes, nb + 28u);
                 const float4 sub = ld_off<float4>(nodes, nb + 48u);  // sub-cells per unit length x 3, sub_first
                 const int prim_count = pc_ie.x;
-                const double cap = min_distance * 0.99;
                 if ((phase & 7) == PH_MARCH && pc_ie.y) {  // Octree.marchRay (octree.ts:250-294): skip the rest of an empty leaf
-                    const float tf0 = to_f32((static_cast<double>(ff0) - ray.od[0]) * inv0), tf1 = to_f32((static_cast<double>(ff1) - ray.od[1]) * inv1),
-                                tf2 = to_f32((static_cast<double>(ff2) - ray.od[2]) * inv2);
+                    const float tf0 = to_f32(ff0 * inv0), tf1 = to_f32(ff1 * inv1), tf2 = to_f32(ff2 * inv2);  // (face - origin) * invDir
                     // JS: tExit = Math.min(...) is NaN when an operand is, and then no comparison holds: skip 0; a NaN tEnter is ignored
                     const bool tf_nan = (tf0 != tf0) | (tf1 != tf1) | (tf2 != tf2);
                     const float xt = __builtin_fminf(__builtin_fminf(tf0, tf1), tf2);
                     bool bad = tf_nan | (xt < 0.0f);
                     const double ahead = static_cast<double>(xt) - t;
                     if (!(ahead > near_margin)) {  // tExit is not clearly ahead (or NaN): the near faces decide (octree.ts:215)
-                        const float tn0 = to_f32((static_cast<double>(fn0) - ray.od[0]) * inv0), tn1 = to_f32((static_cast<double>(fn1) - ray.od[1]) * inv1),
-                                    tn2 = to_f32((static_cast<double>(fn2) - ray.od[2]) * inv2);
+                        const float tn0 = to_f32(ld_off<double>(frame, nb + (far0 ^ 32u)) * inv0), tn1 = to_f32(ld_off<double>(frame, nb + (far1 ^ 32u)) * inv1),
+                                    tn2 = to_f32(ld_off<double>(frame, nb + (far2 ^ 32u)) * inv2);
                         const bool tn_nan = (tn0 != tn0) | (tn1 != tn1) | (tn2 != tn2);
                         const float et = __builtin_fmaxf(__builtin_fmaxf(tn0, tn1), tn2);
                         bad |= !tn_nan & (et > xt);
@@ -778,12 +778,13 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
                         };
                         const int sub_first = __builtin_bit_cast(int32_t, sub.w);
                         if (P.oct_sub_hdr && sub_first >= 0) {  // crowded leaf: the candidates of p's sub-cell
-                            const float lo0 = far0 ? fn0 : ff0, lo1 = far1 >= 16u ? fn1 : ff1, lo2 = far2 >= 16u ? fn2 : ff2;  // the leaf's lower corner
+                            const float lo0 = ld_off<float>(nodes, nb), lo1 = ld_off<float>(nodes, nb + 4u), lo2 = ld_off<float>(nodes, nb + 8u);
                             const int sx = min(max(static_cast<int>((p.x - lo0) * sub.x), 0), RM_OCT_SUB - 1);
                             const int sy = min(max(static_cast<int>((p.y - lo1) * sub.y), 0), RM_OCT_SUB - 1);
                             const int sz = min(max(static_cast<int>((p.z - lo2) * sub.z), 0), RM_OCT_SUB - 1);
-                            const uint32_t hdr =
-                                ld_off<uint32_t>(P.oct_sub_hdr, static_cast<uint32_t>(sub_first + (sz * RM_OCT_SUB + sy) * RM_OCT_SUB + sx) * 4u);
+                            const uint32_t sc = __umul24(__umul24(static_cast<uint32_t>(sz), RM_OCT_SUB) + static_cast<uint32_t>(sy), RM_OCT_SUB) +
+                                                static_cast<uint32_t>(sx);  // 24-bit multiplies: full rate, v_mul_lo_u32 is not
+                            const uint32_t hdr = ld_off<uint32_t>(P.oct_sub_hdr, (static_cast<uint32_t>(sub_first) + sc) * 4u);
                             const uint32_t lb0 = hdr >> 8;
                             const int n_sub = static_cast<int>(hdr & 0xFFu);
                             for (int e = 0; e < n_sub; ++e) {
@@ -844,13 +845,13 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
 
 template <int ACCEL, bool OTHER, int GEN>
 __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
-    // wave tile: tile_w x (64 / tile_w); four waves stacked vertically per workgroup
+    // wave tile: tile_w x (64 / tile_w); the waves of a workgroup (blockDim / 64: option `v1_block`) stacked vertically
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = P.tile_w, th = 64 / tw;
     const int tiles_x = (P.width + tw - 1) / tw;
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
     const int x = bx * tw + (lane % tw);
-    const int row = by * (4 * th) + wave * th + (lane / tw);  // tile-local row
+    const int row = by * (static_cast<int>(blockDim.x >> 6) * th) + wave * th + (lane / tw);  // tile-local row
     const int rows = P.local_rows;
 #ifdef RM_COUNTS
     if (threadIdx.x == 0) rm_cnt_g = P.stamps;
@@ -901,6 +902,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
 
 #ifndef RM_LENGTH_SQRT  // scene-independent kernels exist once (this file is compiled a second time with -DRM_LENGTH_SQRT)
 // ------------------------------------------------------------------ small kernels
+
+// The octree's boxes relative to one camera position (render_kernel_oct): intersectRayBox computes (bounds - origin) * invDir
+// per ray and axis (octree.ts:200-203); the difference does not depend on the ray.
+__global__ __launch_bounds__(256) void oct_frame_table_kernel(const RmOctNode *nodes, int n, double ox, double oy, double oz,
+                                                              RmOctFrameNode *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const RmOctNode nd = nodes[i];
+    RmOctFrameNode f;
+    f.lo[0] = static_cast<double>(nd.lo[0]) - ox;
+    f.lo[1] = static_cast<double>(nd.lo[1]) - oy;
+    f.lo[2] = static_cast<double>(nd.lo[2]) - oz;
+    f.cap = nd.min_distance * 0.99;
+    f.hi[0] = static_cast<double>(nd.hi[0]) - ox;
+    f.hi[1] = static_cast<double>(nd.hi[1]) - oy;
+    f.hi[2] = static_cast<double>(nd.hi[2]) - oz;
+    f.pad = 0.0;
+    out[i] = f;
+}
 
 __global__ __launch_bounds__(256) void shade_kernel(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal,
                                                     const uint16_t *sdf, const uint16_t *iters, uchar4 *rgba, float l0,
@@ -1109,16 +1129,19 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (p.variant == 2 && p.algorithm == 0) return RM_LEN_VARIANT(rm_launch_render_v2)(p, stream, kernel_name);
     const int tw = p.tile_w, th = 64 / tw;
+    const int wpw = p.v1_block >= 256 ? 4 : (p.v1_block >= 128 ? 2 : 1);  // waves per workgroup (option `v1_block`)
+    const int threads = 64 * wpw;
     const int tiles_x = (p.width + tw - 1) / tw;
-    const int tiles_y = (rows + 4 * th - 1) / (4 * th);
-    const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(256);
+    const int tiles_y = (rows + wpw * th - 1) / (wpw * th);
+    const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(static_cast<unsigned>(threads));
     // expression programs keep their position slots and pending values in LDS (rm_program.h)
-    size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+    size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * threads : 0;
     RmRenderParams pl = p;
     pl.v1_list_offset = -1;
-    if (p.accel == 2 && p.v1_lists && p.general < 2 && p.bvh_nodes < 65536 && shmem + 4 * RM_V1_LIST_CAP * 128 <= 64 * 1024) {
+    const size_t list_bytes = static_cast<size_t>(2) * RM_V1_LIST_CAP * threads;
+    if (p.accel == 2 && p.v1_lists && p.general < 2 && p.bvh_nodes < 65536 && shmem + list_bytes <= 64 * 1024) {
         pl.v1_list_offset = static_cast<int32_t>((shmem + 15) & ~static_cast<size_t>(15));  // per-ray hit-leaf lists behind the program slots
-        shmem = static_cast<size_t>(pl.v1_list_offset) + 4 * RM_V1_LIST_CAP * 128;
+        shmem = static_cast<size_t>(pl.v1_list_offset) + list_bytes;
     }
 #define RM_V1(A, O, G)                                                                       \
     {                                                                                        \
@@ -1126,7 +1149,7 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
         if (kernel_name) *kernel_name = "render_kernel<" #A ", " #O ", " #G ">" RM_LEN_TAG;  \
     }
 #define RM_V1A(O, G) { if (p.accel == 2) RM_V1(2, O, G) else if (p.accel == 1) RM_V1(1, O, G) else RM_V1(0, O, G) }
-    if (p.accel == 1 && p.general == 0 && p.algorithm == 0 && p.oct_lean && p.oct_lut && p.oct_recs && p.filter && p.oct_nodes < (1 << 24) &&
+    if (p.accel == 1 && p.general == 0 && p.algorithm == 0 && p.oct_lean && p.oct_frame && p.oct_lut && p.oct_recs && p.filter && p.oct_nodes < (1 << 24) &&
         p.oct_prim_count < (1 << 26)) {  // 32-bit byte offsets into the node and record tables
         // one wave per workgroup, 8 x 8 pixels: wave slots refill one by one (four-wave workgroups wait for a free slot on every
         // SIMD: 3.10 -> 2.89 ms on the 10 000-sphere frame), and a square tile keeps the rays of a wave in the same leaves
@@ -1150,6 +1173,13 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
 }
 
 #ifndef RM_LENGTH_SQRT
+hipError_t rm_launch_oct_frame_table(const RmOctNode *nodes, int n, const double origin[3], RmOctFrameNode *out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(oct_frame_table_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, nodes, n, origin[0], origin[1],
+                       origin[2], out);
+    return hipGetLastError();
+}
+
 hipError_t rm_launch_shade(int shader, int64_t n, const uint8_t *depth, const uint8_t *normal, const uint16_t *sdf,
                            const uint16_t *iters, uint8_t *rgba, const float light[3], hipStream_t stream) {
     if (n <= 0) return hipSuccess;

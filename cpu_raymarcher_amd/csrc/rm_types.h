@@ -42,6 +42,16 @@ struct RmOctNode {
 
 #define RM_OCT_SUB 12  // sub-cells per axis of a crowded octree leaf
 
+// One octree node relative to a camera position (render_kernel_oct): the operands of intersectRayBox's
+// (bounds - origin) * invDir (octree.ts:200-203) and marchRay's minDistance * 0.99 (octree.ts:282), 64 B like RmOctNode so
+// one byte offset addresses both.
+struct RmOctFrameNode {
+    double lo[3];  // (double)lo - origin
+    double cap;    // min_distance * 0.99
+    double hi[3];  // (double)hi - origin
+    double pad;
+};
+
 struct RmSphere {
     float cx, cy, cz;
     float rf;  // (float)radius, used only by the conservative candidate filter
@@ -150,6 +160,7 @@ struct RmRenderParams {
     const uint16_t *pq_list;
     const uint16_t *bvh_leaves;  // v2 bundle cull: node indices of the non-empty leaves, increasing; bvh_leaf_count entries (0: off)
     int32_t bvh_leaf_count;
+    int32_t v1_block;  // v1: threads per workgroup (64, 128 or 256; option `v1_block`)
     int32_t oct_lean;  // v1, octree, sphere scenes with the cell table: the lean sphere-tracer kernel (render_kernel_oct; option `oct_lean`)
     const uint32_t *nn_cells;  // nearest-candidate lists per grid cell (all-primitive fallback)
     const uint16_t *nn_list;
@@ -184,6 +195,7 @@ struct RmRenderParams {
     const int32_t *oct_prims;
     const RmSphereRec *oct_recs;  // parallel to oct_prims (sphere scenes only, else null)
     const int32_t *oct_lut;       // 64^3 finest-level cells -> leaf node index (null: descend the tree)
+    const RmOctFrameNode *oct_frame;  // the nodes relative to this launch's camera position (rm_api.cpp attaches it; null: no lean octree kernel)
     const uint32_t *oct_sub_hdr;  // per crowded leaf RM_OCT_SUB^3 sub-cells: (offset << 8) | count into oct_sub_list
     const uint8_t *oct_sub_list;  // positions within the leaf's record list of the spheres that can be nearest there
     uint8_t *depth;

@@ -99,10 +99,11 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16),
                      dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0),
                      dict(kernel=2, n0_batch=1), dict(kernel=2, n0_batch=16, refill=24), dict(kernel=2, n0_batch=8, uniform=0, cull=0),
-                     dict(kernel=2, lpt=0), dict(kernel=2, lpt=1), dict(kernel=2, lpt=1, item_px=64, tile_w=32)]:
+                     dict(kernel=2, lpt=0), dict(kernel=2, lpt=1), dict(kernel=2, lpt=1, item_px=64, tile_w=32),
+                     dict(kernel=1, oct_lean=0), dict(kernel=1, oct_lean=0, v1_block=256, tile_w=16), dict(kernel=1, v1_block=128, tile_w=32)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
                              hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32, cull=1,
-                             n0_batch=64, lpt=1).items():
+                             n0_batch=64, lpt=1, oct_lean=1, v1_block=64).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -217,6 +218,61 @@ def test_frames_in_flight_on_separate_streams(rm):
     for k in range(len(yaws)):
         for name in sets[k]:
             assert torch.equal(sets[k][name], alone[k][name]), (k, name)
+    ctx.close()
+
+
+def test_lean_octree_kernel_and_its_camera_tables(rm, oracle):
+    """render_kernel_oct (sphere scenes, octree with the cell table) against render_kernel<1, false, 0> and the oracle:
+    cameras inside and outside the root cube (the all-primitive fallback), rays parallel to an axis (zero direction
+    components: infinite 1 / d), more camera positions than the ring of origin-relative node tables holds, and frames
+    in flight on several streams that share and replace those tables."""
+    import torch
+    ctx = rm.Context(0)
+    sp = oracle.synthetic_spheres(1500)
+    W, H = 200, 120
+    for preset, spheres, angs in [(3, None, [(0.0, 0.0), (0.3, 0.7), (-1.2, 2.5), (1.5, 0.0)]), (None, sp, [(0.0, 0.0), (0.25, 0.6), (-0.4, 3.0)]),
+                                  (2, None, [(0.0, 0.0), (0.2, -0.9)])]:
+        for ang in angs:
+            outs = {}
+            for lean in (1, 0):
+                ctx.set_option("oct_lean", lean)
+                outs[lean] = gpu_render(rm, ctx, preset, "Octree", W, H, ang, spheres=spheres)
+                assert ("render_kernel_oct" in ctx.last_kernel()) == bool(lean), ctx.last_kernel()
+            assert_same(outs[1], outs[0], "lean vs generic octree kernel %s %s" % (preset, ang))
+            assert_same(outs[1], cpu_render(oracle, preset, "Octree", W, H, ang, spheres=spheres), "lean octree kernel vs oracle %s %s" % (preset, ang))
+    ctx.set_option("oct_lean", 1)
+    # 40 camera positions > 32 table slots, four streams, every frame against the same frame rendered alone
+    dev = torch.device("cuda:0")
+    scene = rm.Scene("Octree", ctx=ctx)
+    scene.loadSpheres(sp[:, :3], sp[:, 3])
+    tracer = rm.SphereTracer()
+    yaws = [0.16 * k for k in range(40)]
+
+    def buffers():
+        return [torch.zeros(W * H, dtype=torch.uint8, device=dev), torch.zeros(3 * W * H, dtype=torch.uint8, device=dev),
+                torch.zeros(W * H, dtype=torch.int16, device=dev), torch.zeros(W * H, dtype=torch.int16, device=dev)]
+
+    def render(b, yaw):
+        scene.camera.setAngles(0.2, yaw)
+        tracer.runRaymarcher(scene, *b, W, H, 0.0)
+
+    alone = []
+    for yaw in yaws:
+        b = buffers()
+        render(b, yaw)
+        torch.cuda.synchronize()
+        alone.append([v.clone() for v in b])
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    sets = [buffers() for _ in yaws]
+    for rep in range(2):
+        for k, yaw in enumerate(yaws):
+            with torch.cuda.stream(streams[k % 4]):
+                render(sets[k], yaw)
+                render(sets[k], yaw)  # the same camera again: shares the table
+    torch.cuda.synchronize()
+    for k in range(len(yaws)):
+        for a, b in zip(sets[k], alone[k]):
+            assert torch.equal(a, b), k
     ctx.close()
 
 

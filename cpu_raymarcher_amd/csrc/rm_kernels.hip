@@ -59,8 +59,17 @@ __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_
     if (GEN >= 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
         for (int k = 0; k < n; ++k) {
             const int obj = ids ? ids[k] : k;
-            closest = js_min_nan(program_sdf<GEN == 3>(P.prog, P.obj_ranges[2 * obj], P.obj_ranges[2 * obj + 1], p, P.time, P.prog_slots),
-                                 closest);
+            // The interpreter reads its instruction stream through the scalar cache, so it runs ONE object at a time: lanes whose
+            // lists name different objects at this position (different leaves) take turns (a waterfall over the distinct ids).
+            double d = 0.0;
+            for (bool done = false; !done;) {
+                const int u = __builtin_amdgcn_readfirstlane(obj);
+                if (obj == u) {
+                    d = program_sdf<GEN == 3>(P.prog, P.obj_ranges[2 * u], P.obj_ranges[2 * u + 1], p, P.time, P.prog_slots);
+                    done = true;
+                }
+            }
+            closest = js_min_nan(d, closest);
         }
         return closest;
     }

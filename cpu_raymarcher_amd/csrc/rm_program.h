@@ -1,8 +1,9 @@
 // rm_program.h -- device interpreter for SDF expression programs (RmInstr, rm_types.h):
 // Primitive.sdf (primitive.ts:33-39) of Round / SmoothUnion / SmoothSubtraction / Twist / Repetition /
 // AnimatedTranslate (primitive_operations/*.ts) over Sphere / Box / Torus / Mandelbulb leaves.
-// Every wave executes the instruction stream of one object uniformly (the program counter and the
-// slot indices are wave-uniform); only the Mandelbulb's escape loop diverges per lane.
+// Every wave executes the instruction stream of one object uniformly (the caller, list_min in rm_kernels.hip, lets lanes
+// with different objects take turns; the program counter and the slot indices are wave-uniform and the stream is read
+// through the scalar cache); only the Mandelbulb's escape loop diverges per lane.
 #pragma once
 #include "rm_device.h"
 #include "rm_jsmath.h"
@@ -15,6 +16,45 @@ extern __shared__ __align__(16) unsigned char rm_prog_smem[];
 
 namespace rmd {
 
+// The instruction stream is the same for every lane: read it through the scalar cache.  A pointer handed to an out-of-line
+// function arrives in VGPRs as a generic pointer, and every field read became a flat_load with a full wait behind it
+// (three or four dependent round trips per interpreted instruction); made wave-uniform and typed as constant address
+// space, the same reads are s_load_dwordx4/x8/x16 into SGPRs that the VALU instructions use directly.
+typedef const RmInstr __attribute__((address_space(4))) *RmInstrConstPtr;
+__device__ __forceinline__ RmInstrConstPtr uniform_program(const RmInstr *prog) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(prog);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(a)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(a >> 32));
+    return reinterpret_cast<RmInstrConstPtr>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// What every instruction needs, requested in ONE batch at the top of the interpreter loop: the last 64 bytes of the record
+// (six parameters, op, src, dst, flags: one s_load_dwordx16) and the translation columns of T and Tinv (all a pure
+// translation needs).  Read field by field the record cost three or four dependent scalar-cache round trips.
+typedef int rm_i32x16 __attribute__((ext_vector_type(16)));
+typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
+struct InstrHead {
+    double p[6];
+    int op, src, dst, flags;
+    float t[3], ti[3];  // T[12..14], Tinv[12..14]
+};
+__device__ __forceinline__ InstrHead load_head(RmInstrConstPtr I) {
+    const rm_i32x16 w = *reinterpret_cast<const rm_i32x16 __attribute__((address_space(4))) *>(&I->p[0]);
+    const rm_f32x4 t = *reinterpret_cast<const rm_f32x4 __attribute__((address_space(4))) *>(&I->T[12]);
+    const rm_f32x4 ti = *reinterpret_cast<const rm_f32x4 __attribute__((address_space(4))) *>(&I->Tinv[12]);
+    InstrHead h;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        h.p[k] = __builtin_bit_cast(double, (static_cast<unsigned long long>(static_cast<unsigned int>(w[2 * k + 1])) << 32) |
+                                                static_cast<unsigned int>(w[2 * k]));
+    h.op = w[12];
+    h.src = w[13];
+    h.dst = w[14];
+    h.flags = w[15];
+    h.t[0] = t[0], h.t[1] = t[1], h.t[2] = t[2];
+    h.ti[0] = ti[0], h.ti[1] = ti[1], h.ti[2] = ti[2];
+    asm volatile("" ::"s"(h.op), "s"(h.t[0]), "s"(h.ti[0]));  // keep the three loads together here (not sunk into the branches that use them)
+    return h;
+}
 // Math.min / Math.max: NaN if either argument is NaN (the Mandelbulb can produce NaN at its pole)
 __device__ __forceinline__ double js_min_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
 __device__ __forceinline__ double js_max_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
@@ -27,8 +67,8 @@ __device__ __forceinline__ double js_max_nan(double a, double b) { return (a != 
 // (translations, and the identity itself for the smooth unions): 1*x + 0*y + 0*z + t = x + t for every
 // finite point, signed zeros included (the trailing + t absorbs them), and f32(f64(x) + f64(t)) equals the
 // binary32 sum (double rounding is innocuous for + when the wide format has >= 2p+2 bits): one v_add_f32.
-__device__ __forceinline__ void transform_mat4(const float *m, int flags, float fx, float fy, float fz, float &ox, float &oy,
-                                               float &oz) {
+template <typename MatPtr>
+__device__ __forceinline__ void transform_mat4(MatPtr m, int flags, float fx, float fy, float fz, float &ox, float &oy, float &oz) {
     if (flags & 4) {
         ox = fx + m[12];
         oy = fy + m[13];
@@ -49,6 +89,18 @@ __device__ __forceinline__ void transform_mat4(const float *m, int flags, float 
     oz = to_f32((m[2] * x + m[6] * y + m[10] * z + m[14]) / w);
 }
 
+// transform_mat4 with the translation column already at hand
+template <typename MatPtr>
+__device__ __forceinline__ void transform_head(MatPtr m, const float *tcol, int flags, float fx, float fy, float fz, float &ox, float &oy, float &oz) {
+    if (flags & 4) {
+        ox = fx + tcol[0];
+        oy = fy + tcol[1];
+        oz = fz + tcol[2];
+        return;
+    }
+    transform_mat4(m, flags, fx, fy, fz, ox, oy, oz);
+}
+
 // Out-of-line copies for the Mandelbulb's escape loop: inlined, the five fdlibm bodies push the kernel to 226
 // VGPRs (2 waves/SIMD); as calls the register need is the largest callee's, not their sum.
 __device__ __attribute__((noinline)) double mb_atan2(double y, double x) { return js_atan2(y, x); }
@@ -58,7 +110,8 @@ __device__ __attribute__((noinline)) void mb_pow_pair(double x, double ya, doubl
 __device__ __attribute__((noinline)) void mb_sincos(double x, double &s, double &c) { js_sincos(x, s, c); }
 
 // mandelbulb.ts:37-78; z is a Float32Array: each component store rounds to binary32
-__device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, float lz, double time) {
+template <typename PrmPtr>
+__device__ inline double mandelbulb_sdf(PrmPtr prm, float lx, float ly, float lz, double time) {
     const double power = prm[0], speed = prm[3];
     const int iterations = static_cast<int>(prm[1]);
     const bool animate = prm[2] != 0.0;
@@ -91,8 +144,11 @@ __device__ inline double mandelbulb_sdf(const double *prm, float lx, float ly, f
 // code doubles the register need (200 against 106 VGPRs), so scenes without one get an instantiation that runs
 // four waves per SIMD instead of two.
 template <bool MB>
-__device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int first, int count, const Vec3f &p, double time,
-                                                        int n_slots) {
+__device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog_, int first_, int count_, const Vec3f &p, double time,
+                                                        int n_slots_) {
+    const RmInstrConstPtr prog = uniform_program(prog_);
+    const int first = __builtin_amdgcn_readfirstlane(first_), count = __builtin_amdgcn_readfirstlane(count_),
+              n_slots = __builtin_amdgcn_readfirstlane(n_slots_);
     const int nt = blockDim.x, tid = threadIdx.x;
     float *pos = reinterpret_cast<float *>(rm_prog_smem) + tid;                              // [(s*3 + c) * nt]
     double *val = reinterpret_cast<double *>(rm_prog_smem + static_cast<size_t>(n_slots) * 3 * nt * 4) + tid;  // [k * nt]
@@ -100,15 +156,17 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
     pos[0] = p.x;
     pos[nt] = p.y;
     pos[2 * nt] = p.z;
+    // (requesting the NEXT instruction's head one trip ahead was measured slower: 4.36 against 3.75 ms on the Chicken preset)
     for (int pc = first; pc < first + count; ++pc) {
-        const RmInstr &I = prog[pc];
-        const int op = I.op;
+        const RmInstrConstPtr I = prog + pc;
+        const InstrHead H = load_head(I);
+        const int op = H.op;
         if (op >= 20) {  // POST
             if (op == 20) {  // round.ts:24
-                val[(sp - 1) * nt] = val[(sp - 1) * nt] - I.p[0];
+                val[(sp - 1) * nt] = val[(sp - 1) * nt] - H.p[0];
             } else {
                 const double d1 = val[(sp - 2) * nt], d2 = val[(sp - 1) * nt];
-                const double k = I.p[0] * 4.0;
+                const double k = H.p[0] * 4.0;
                 sp -= 1;
                 if (op == 21) {  // smoothUnion.ts:31-34
                     const double h = js_max_nan(k - __builtin_fabs(d1 - d2), 0.0);
@@ -122,26 +180,26 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
         }
         float lx, ly, lz;
         {
-            const float *src = pos + I.src * 3 * nt;
-            transform_mat4(I.T, (I.flags & 1) | ((I.flags >> 2) & 1) << 2, src[0], src[nt], src[2 * nt], lx, ly, lz);  // primitive.ts:34-35
+            const float *src = pos + H.src * 3 * nt;
+            transform_head(I->T, H.t, (H.flags & 1) | ((H.flags >> 2) & 1) << 2, src[0], src[nt], src[2 * nt], lx, ly, lz);  // primitive.ts:34-35
         }
         if (op < 10) {  // leaves
             double d;
             if (op == 1) {  // box.ts:13-30
-                const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - I.p[0]);
-                const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - I.p[1]);
-                const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - I.p[2]);
+                const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - H.p[0]);
+                const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - H.p[1]);
+                const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - H.p[2]);
                 const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
                 const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
                 d = vec3_length(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
             } else if (op == 2) {  // torus.ts:14-25
                 const double dx = lx, dy = ly, dz = lz;
-                const double qx = __builtin_sqrt(dx * dx + dz * dz) - I.p[0];
-                d = __builtin_sqrt(qx * qx + dy * dy) - I.p[1];
+                const double qx = __builtin_sqrt(dx * dx + dz * dz) - H.p[0];
+                d = __builtin_sqrt(qx * qx + dy * dy) - H.p[1];
             } else if (MB && op == 3) {
-                d = mandelbulb_sdf(I.p, lx, ly, lz, time);
+                d = mandelbulb_sdf(H.p, lx, ly, lz, time);
             } else {  // sphere.ts:12-14
-                d = vec3_length(lx, ly, lz) - I.p[0];
+                d = vec3_length(lx, ly, lz) - H.p[0];
             }
             val[sp * nt] = d;
             sp += 1;
@@ -150,14 +208,14 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
         // PRE: the point the operands see
         float wx, wy, wz;
         if (op == 15) {  // animatedTranslate.ts:34-49: local - direction * (sin(time*speed)*amplitude)
-            const double offset = js_sin(time * I.p[4]) * I.p[3];
-            wx = to_f32(static_cast<double>(lx) - static_cast<double>(to_f32(I.p[0] * offset)));
-            wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(I.p[1] * offset)));
-            wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(I.p[2] * offset)));
+            const double offset = js_sin(time * H.p[4]) * H.p[3];
+            wx = to_f32(static_cast<double>(lx) - static_cast<double>(to_f32(H.p[0] * offset)));
+            wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(H.p[1] * offset)));
+            wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(H.p[2] * offset)));
         } else {
-            transform_mat4(I.Tinv, ((I.flags >> 1) & 1) | ((I.flags >> 3) & 1) << 2, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
+            transform_head(I->Tinv, H.ti, ((H.flags >> 1) & 1) | ((H.flags >> 3) & 1) << 2, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
             if (op == 13) {  // twist.ts:21-33
-                const double a = I.p[0] * static_cast<double>(wy);
+                const double a = H.p[0] * static_cast<double>(wy);
                 double c, s;
                 js_sincos(a, s, c);
                 const float tx = to_f32(c * static_cast<double>(wx) - s * static_cast<double>(wz));
@@ -165,12 +223,12 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog, int
                 wx = tx;
                 wz = tz;
             } else if (op == 14) {  // repetition.ts:20-24
-                wx = to_f32(static_cast<double>(wx) - I.p[0] * js_round(static_cast<double>(wx) / I.p[0]));
-                wy = to_f32(static_cast<double>(wy) - I.p[1] * js_round(static_cast<double>(wy) / I.p[1]));
-                wz = to_f32(static_cast<double>(wz) - I.p[2] * js_round(static_cast<double>(wz) / I.p[2]));
+                wx = to_f32(static_cast<double>(wx) - H.p[0] * js_round(static_cast<double>(wx) / H.p[0]));
+                wy = to_f32(static_cast<double>(wy) - H.p[1] * js_round(static_cast<double>(wy) / H.p[1]));
+                wz = to_f32(static_cast<double>(wz) - H.p[2] * js_round(static_cast<double>(wz) / H.p[2]));
             }
         }
-        float *dst = pos + I.dst * 3 * nt;
+        float *dst = pos + H.dst * 3 * nt;
         dst[0] = wx;
         dst[nt] = wy;
         dst[2 * nt] = wz;

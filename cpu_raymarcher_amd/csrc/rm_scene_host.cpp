@@ -883,6 +883,14 @@ struct Forest {
             }
         }
     }
+    // spheres, boxes and tori under Round / SmoothUnion / SmoothSubtraction only
+    bool plain_subtree(int i) const {
+        const NodeDesc &d = nodes[i];
+        if (d.type < 10) return d.type == 0 || d.type == 1 || d.type == 2;
+        if (d.type == 10) return plain_subtree(d.a);
+        if (d.type == 11 || d.type == 12) return plain_subtree(d.a) && plain_subtree(d.b);
+        return false;
+    }
     // post-order instruction stream of the subtree rooted at i, reading its point from slot `slot`
     mutable int max_slot = 0, max_vals = 0;
     bool compile(int i, int slot, int &depth_vals, std::vector<RmInstr> &out, std::string &err) const {
@@ -919,10 +927,21 @@ struct Forest {
             }
             return true;
         }
-        out.push_back(ins);  // PRE
-        if (!compile(d.a, slot + 1, depth_vals, out, err)) return false;
+        // A Round / SmoothUnion / SmoothSubtraction node whose transform is the identity hands its point on unchanged
+        // (transformMat4 by the identity and back: x*1 + 0 + 0 + 0, exact but for the sign of a zero coordinate): its PRE half
+        // is dropped and the operands read the node's own slot.  Only above spheres, boxes and tori, whose distances do not
+        // depend on the sign of a zero (|x|, x*x, hypot); a Twist or Mandelbulb below keeps the reference's every step.
+        auto identity = [](const float *m) {
+            for (int k = 0; k < 16; ++k)
+                if (m[k] != ((k % 5 == 0) ? 1.0f : 0.0f)) return false;
+            return true;
+        };
+        const bool pass_through = d.type >= 10 && d.type <= 12 && identity(ins.T) && identity(ins.Tinv) && plain_subtree(i);
+        const int child_slot = pass_through ? slot : slot + 1;
+        if (!pass_through) out.push_back(ins);  // PRE
+        if (!compile(d.a, child_slot, depth_vals, out, err)) return false;
         const bool binary = d.type == 11 || d.type == 12;
-        if (binary && !compile(d.b, slot + 1, depth_vals, out, err)) return false;
+        if (binary && !compile(d.b, child_slot, depth_vals, out, err)) return false;
         if (binary || d.type == 10) {
             ins.op = d.type + 10;  // POST
             out.push_back(ins);

@@ -100,10 +100,14 @@ def test_error_codes_without_a_device(rm):
     ctx.scene_from_preset(99, 2)  # scene.ts:39 clamps to preset 18 ("67")
     assert ctx.scene_info()["n_prims"] == 2
     ident = np.eye(4, dtype=np.float32).ravel()
-    chain = [(0, -1, -1, ident, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)]  # 20 nested Round operators
+    moved = ident.copy()
+    moved[12] = 0.25  # a Round takes its operand's transform (round.ts): translated, every level needs a position slot of its own
+    chain = [(0, -1, -1, moved, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)]  # 20 nested Round operators
     with pytest.raises(rm.RmUnsupported):
         ctx.scene_from_nodes(chain, [len(chain) - 1], 0)
     ctx.scene_from_nodes(chain[:10], [9], 2)
+    assert ctx.scene_info()["n_prims"] == 1
+    ctx.scene_from_nodes([(0, -1, -1, ident, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)], [20], 0)  # identity transforms pass the point through: no slot per level
     assert ctx.scene_info()["n_prims"] == 1
     with pytest.raises(rm.RmError):  # operands must precede their operator
         ctx.scene_from_nodes([(10, 1, -1, None, [0.1]), (0, -1, -1, ident, [0.5])], [0], 0)

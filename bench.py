@@ -216,6 +216,9 @@ def main():
                     help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
                          "(main.ts:438-441) and report the per-frame metric series (main.ts:550-566); N = 1 only")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (rm_set_option)")
+    ap.add_argument("--tail-ramp", type=int, default=4,
+                    help="N > 0 (one GPU, frames in flight): the last N frames of the timed burst launch with N - (frames after them) persistent "
+                         "workgroups per CU instead of 1 (max 4): they find fewer and fewer other frames beside them.  0: off")
     ap.add_argument("--frames-in-flight", type=int, default=12,
                     help="frames enqueued concurrently, each on its own HIP stream with its own buffers: the tail of a "
                          "frame's persistent kernel (its slowest rays) overlaps the next frames; 1 = strictly serial")
@@ -329,10 +332,14 @@ def main():
         frame_no = [0]
         series = []  # analytics sweep: one accumulator per frame, read after the timed region
 
-        def step(timed):
+        def step(timed, remaining=None):
             k = frame_no[0] % S
             frame_no[0] += 1
             b = sets[k]
+            if remaining is not None and args.tail_ramp and "blocks_per_cu" in in_flight_opts:
+                # the last frames of the burst find fewer and fewer other frames beside them: each brings more persistent
+                # workgroups of its own (4 = the library's default for a frame that runs alone)
+                ctx.set_option("blocks_per_cu", max(1, min(4, args.tail_ramp - remaining)) if remaining < args.tail_ramp else 1)
             if args.analytics_sweep:
                 scene.camera.rotateCamera(0, 0.015)  # main.ts:438-441
             with torch.cuda.stream(streams[k]):
@@ -505,11 +512,15 @@ def main():
     finish()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        if world == 1:
+            step(True, args.steps - 1 - i)
+        else:
+            step(True)
     finish()
     sync()
     elapsed = time.perf_counter() - t0
+    apply_opts(True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -604,6 +615,7 @@ def main():
                          "achieved_in_flight": achieved_in_flight, "frac_in_flight": achieved_in_flight / HBM_PEAK_GBPS,
                          "kernel_in_flight": kernel_in_flight, "kernel_ms_in_flight": kern_ms_in_flight,
                          "frames_in_flight": S, "in_flight_options": {k: v for k, (v, _) in in_flight_opts.items()},
+                         "tail_ramp": (args.tail_ramp if (world == 1 and "blocks_per_cu" in in_flight_opts) else 0),
                          "basis_in_flight": "device level: algorithmic bytes per launch x %d launches / wall time of the "
                                             "timed region (launches overlap)" % n_launches,
                          "valu": valu,

@@ -18,6 +18,11 @@ for w in C3 C2 C5; do
   cp $(ls -S gpurun_out/prof_r02_$w/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats_$w.csv 2>/dev/null || true
 done
 cd $R
+# the `valu` block: the instruction mix priced with the measured issue costs needs the kernels' listings (built here: same
+# compiler, same sources as the library that travelled)
+make -s -C cpu_raymarcher_amd/csrc asm > gpurun_out/asm.log 2>&1 && python scripts/price_valu.py C3 C2 C5 > gpurun_out/price_valu.log 2>&1 || echo "price_valu failed (see gpurun_out/price_valu.log)"
+cp profiles/r02/pmc_C3.json profiles/r02/pmc_C2.json profiles/r02/pmc_C5.json gpurun_out/profiles_r02/ 2>/dev/null || true
+tail -3 gpurun_out/price_valu.log
 line() {  # name, bench args...
   local name=$1; shift
   timeout -k 10 400 python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err

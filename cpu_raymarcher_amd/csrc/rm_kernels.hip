@@ -618,6 +618,16 @@ __device__ double ray_march_other(const RmRenderParams &P, const Ray &ray, uint3
     return t;
 }
 
+// Workgroup id -> tile for the one-ray-per-lane kernels.  Workgroups go to the eight XCDs round-robin (id % 8), each with
+// its own L2; a wave tile is 8 pixels wide, so a tile row writes 32-byte pieces of 128-byte lines.  Tiles are therefore
+// dealt in runs of eight: ids 0, 8, 16 ... 56 (all on XCD 0, back to back) are tiles 0 ... 7, ids 1, 9, ... are tiles
+// 8 ... 15, and so on: the pieces of a line meet in one L2 and leave as whole lines.  (The launcher rounds the grid up to
+// a multiple of 64; ids past the last tile return.)
+__device__ __forceinline__ int v1_tile_of_block(int b) {
+    const int r = b & 63;
+    return (b & ~63) + ((r & 7) << 3) + (r >> 3);
+}
+
 // ------------------------------------------------------------------ the octree sphere tracer, lean form
 //
 // render_kernel<1, false, 0> spends 60 % of its instructions in the part of the march step that precedes the distance
@@ -675,7 +685,8 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = P.tile_w, th = 64 / tw;
     const int tiles_x = (P.width + tw - 1) / tw;
-    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int tile = v1_tile_of_block(static_cast<int>(blockIdx.x));
+    const int bx = tile % tiles_x, by = tile / tiles_x;
     const int x = bx * tw + (lane % tw);
     const int wpw = static_cast<int>(blockDim.x >> 6);             // waves per workgroup (the launcher uses 1)
     const int row = by * (wpw * th) + wave * th + (lane / tw);  // tile-local row
@@ -858,7 +869,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = P.tile_w, th = 64 / tw;
     const int tiles_x = (P.width + tw - 1) / tw;
-    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int tile = v1_tile_of_block(static_cast<int>(blockIdx.x));
+    const int bx = tile % tiles_x, by = tile / tiles_x;
     const int x = bx * tw + (lane % tw);
     const int row = by * (static_cast<int>(blockDim.x >> 6) * th) + wave * th + (lane / tw);  // tile-local row
     const int rows = P.local_rows;
@@ -1142,7 +1154,7 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
     const int threads = 64 * wpw;
     const int tiles_x = (p.width + tw - 1) / tw;
     const int tiles_y = (rows + wpw * th - 1) / (wpw * th);
-    const dim3 grid(static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y)), block(static_cast<unsigned>(threads));
+    const dim3 grid((static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y) + 63u) & ~63u), block(static_cast<unsigned>(threads));  // v1_tile_of_block
     // expression programs keep their position slots and pending values in LDS (rm_program.h)
     size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * threads : 0;
     RmRenderParams pl = p;
@@ -1164,7 +1176,7 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
         // SIMD: 3.10 -> 2.89 ms on the 10 000-sphere frame), and a square tile keeps the rays of a wave in the same leaves
         pl.tile_w = 8;
         const int ty = (rows + 7) / 8;
-        hipLaunchKernelGGL(render_kernel_oct, dim3(static_cast<unsigned>((p.width + 7) / 8) * static_cast<unsigned>(ty)), dim3(64), 0, stream,
+        hipLaunchKernelGGL(render_kernel_oct, dim3((static_cast<unsigned>((p.width + 7) / 8) * static_cast<unsigned>(ty) + 63u) & ~63u), dim3(64), 0, stream,
                            pl);  // the lean octree sphere tracer (finite camera: rm_api.cpp)
         if (kernel_name) *kernel_name = "render_kernel_oct" RM_LEN_TAG;
     } else if (p.general == 3) {

@@ -413,8 +413,10 @@ def test_empty_scene_and_bad_inputs(rm, gpu_ctx, oracle):
     with pytest.raises(rm.RmError):
         rm.SphereTracer().runRaymarcher(sc, *bufs, 4, 4, float("inf"))  # non-finite Job.time
     ident = np.eye(4, dtype=np.float32).ravel()
+    moved = ident.copy()
+    moved[12] = 0.25  # a Round takes its operand's transform: translated, every level needs a position slot (identity ones pass through)
     with pytest.raises(rm.RmUnsupported):  # deeper than the interpreter's position-slot file
-        sc.loadNodes([(0, -1, -1, ident, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)], [20])
+        sc.loadNodes([(0, -1, -1, moved, [0.5])] + [(10, i, -1, None, [0.01]) for i in range(20)], [20])
     sc.camera.pitch = float("nan")
     with pytest.raises(rm.RmError):
         rm.SphereTracer().runRaymarcher(sc, *bufs, 4, 4)

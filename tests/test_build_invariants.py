@@ -16,9 +16,9 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="hipcc / c++filt not present")
 
 
-def resource_usage(extra=()):
+def resource_usage(extra=(), source="rm_render_v2.hip"):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
-                          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, "rm_render_v2.hip"), *extra],
+                          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, source), *extra],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
     rows, cur = [], None
     for line in out.split("\n"):
@@ -46,3 +46,13 @@ def test_v2_render_kernels_do_not_spill_vgprs(extra):
     assert headline and headline[0]["ScratchSize [bytes/lane]"] == 0, headline
     # five waves per SIMD in the default build; the sqrt build is compiled for four (full-range IEEE sqrt needs the registers)
     assert headline[0]["Occupancy [waves/SIMD]"] >= (4 if extra else 5), headline
+
+
+@pytest.mark.parametrize("extra", [(), ("-DRM_LENGTH_SQRT",)])
+def test_lean_octree_kernel_keeps_eight_waves_without_spills(extra):
+    """render_kernel_oct is compiled for 64 VGPRs (eight waves per SIMD: its speed against render_kernel<1, false, 0> is
+    occupancy as much as instruction count); a change that makes it spill VGPRs to scratch shows up here, not as a slow frame."""
+    usage = resource_usage(extra, "rm_kernels.hip")
+    k = [r for n, r in usage.items() if n.startswith("render_kernel_oct(")]
+    assert len(k) == 1, sorted(usage)
+    assert k[0]["VGPRs Spill"] == 0 and k[0]["ScratchSize [bytes/lane]"] == 0 and k[0]["Occupancy [waves/SIMD]"] == 8, k[0]

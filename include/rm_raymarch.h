@@ -320,7 +320,7 @@ RM_API int rm_selftest_recip(rm_ctx *ctx, int mode, uint64_t *mismatches);
 RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 
 /* Diagnostic builds only (make EXTRA=-DRM_COUNTS): reads and clears the execution counts of sixteen events of the
- * v2 wave loop -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
+ * v2 wave loop (scripts/counts.py) or of the v1 octree kernels (scripts/counts_v1.py) -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
 RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
 
 /* Kernel-variant knobs for measurement; unknown keys or values are RM_E_INVALID.  They NEVER change results
@@ -341,6 +341,12 @@ RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
  *                 lanes waiting that trigger that round early (64: never early; default 64)
  *   lpt 0|1       v2: hand out a launch's work items longest-first using the item costs the previous launch recorded (any
  *                 order gives the same bytes; shortens the tail of a frame that runs alone; default 1)
+ *   v1_lists 0|1  v1 BVH kernels: per-ray hit-leaf lists (as v2) instead of one tree walk per interval advance (default 1)
+ *   v1_block 64|128|256  v1 kernels: threads per workgroup (default 64: one wave, so wave slots refill one by one); without an
+ *                 explicit tile_w the v1 kernels use 8 x 8-pixel wave tiles
+ *   oct_lean 0|1  octree + sphere scene + sphere tracer: the lean kernel render_kernel_oct (march and getNormal as phases of one
+ *                 loop, eight waves per SIMD, node boxes relative to the camera position from a per-camera table) instead of
+ *                 render_kernel<1, false, 0> (default 1; needs recs, lut and filter on)
  * The one option that is NOT a measurement knob but part of the numeric contract:
  *   length 0|1    gl-matrix vec3.length / vec3.distance (sphere.ts:12-14, box.ts:26,33, mandelbulb.ts:46, smoothUnion.ts:45):
  *                 0 = Math.hypot(x, y, z) (gl-matrix 3.0 - 3.4.3, default), 1 = Math.sqrt(x*x + y*y + z*z) (the form a later

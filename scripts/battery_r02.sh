@@ -31,7 +31,7 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
 print("%-28s %9.1f %-9s kernel alone %.3f ms frac %.4f traffic %s valu %s" % (sys.argv[1].split("bench_")[-1], d["value"], d["unit"], r.get("kernel_ms", 0), r["frac"], r.get("traffic"),
-      (r.get("valu") or {}).get("frac_of_issue_floor")))
+      (r.get("valu") or {}).get("frac")))
 PY
 }
 line C3

@@ -75,7 +75,7 @@ struct rm_ctx {
     bool tile_w_set = false;  // rm_set_option("tile_w") was called: the value then holds for every kernel (else v1 kernels use 8 x 8 wave tiles)
     int64_t opt_filter = 1;
     int64_t opt_lds = 1;
-    int64_t opt_kernel = 0;  // 0 = auto: v2 for BVH / no acceleration, v1 for the octree (measured faster)
+    int64_t opt_kernel = 0;  // 0 = auto: v2 for BVH / no acceleration, v1 for the octree (its lean kernel for sphere scenes: opt_oct_lean) and small scenes
     int64_t opt_list_cap = 32;
     int64_t opt_coop = 1;
     int64_t opt_grid = 1;

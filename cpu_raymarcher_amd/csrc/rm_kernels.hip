@@ -1,7 +1,8 @@
 // rm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the sphere-tracing render path.
 //
-// One ray per lane.  A 64-lane wavefront owns a tile_w x (64 / tile_w) pixel tile, a
-// 256-thread workgroup four such tiles stacked vertically.  There is no dense contraction
+// One ray per lane.  A 64-lane wavefront owns a tile_w x (64 / tile_w) pixel tile (8 x 8 unless option tile_w says
+// otherwise); a workgroup is one wave (option v1_block: up to four tiles stacked vertically) and workgroup ids are dealt
+// to tiles in runs of eight per XCD (v1_tile_of_block).  There is no dense contraction
 // anywhere on this path, so no MFMA: the work is FP64 VALU (the reference computes in JS
 // doubles) with binary32 rounding exactly where the reference stores into Float32Array,
 // plus f32 compares for box tests.  Build with -ffp-contract=off: JS never fuses a*b+c.

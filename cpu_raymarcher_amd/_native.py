@@ -110,6 +110,8 @@ SIGNATURES = {
     "rm_selftest_fastdiv": (C.c_int, [_VP, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]),
     "rm_selftest_recip": (C.c_int, [_VP, C.c_int, _VP]),
     "rm_debug_read_stamps": (C.c_int, [_VP, _VP]),
+    "rm_debug_read_wave_times": (C.c_int, [_VP, _VP]),
+    "rm_debug_read_batch_log": (C.c_int, [_VP, _VP]),
     "rm_debug_read_counts": (C.c_int, [_VP, _VP]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
     "rm_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -612,8 +612,8 @@ int rm_create(int device, rm_ctx **out) {
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), 40 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, 40 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), (40 + 3 * 8192 + 2048 * 48) * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, (40 + 3 * 8192 + 2048 * 48) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(ctx->d_stamps + 6, 0xFF, sizeof(unsigned long long));
         if (e != hipSuccess) {
             delete ctx;
@@ -1182,6 +1182,28 @@ int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8) {
     RM_HIP(ctx, hipMemcpy(out8, ctx->d_stamps, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     RM_HIP(ctx, hipMemset(ctx->d_stamps, 0, 8 * sizeof(uint64_t)));
     RM_HIP(ctx, hipMemset(ctx->d_stamps + 6, 0xFF, sizeof(uint64_t)));  // slot 6: minimum start time of the next launch's waves
+    return RM_OK;
+}
+
+// -DRM_STAMPS builds: start / end time (s_memrealtime, 100 MHz) of the first 8192 waves of the last v2 launch
+int rm_debug_read_wave_times(rm_ctx *ctx, uint64_t *out16384) {
+    if (!ctx || !out16384) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());
+    RM_HIP(ctx, hipMemcpy(out16384, ctx->d_stamps + 40, 3 * 8192 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    RM_HIP(ctx, hipMemset(ctx->d_stamps + 40, 0, 3 * 8192 * sizeof(uint64_t)));
+    return RM_OK;
+}
+
+// -DRM_STAMPS -DRM_STAMPS_LOG builds: the low 32 bits of s_memrealtime at the start of the first 96 batches of the first 2048 waves
+int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608) {
+    if (!ctx || !out196608) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());
+    RM_HIP(ctx, hipMemcpy(out196608, ctx->d_stamps + 40 + 3 * 8192, 2048 * 96 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RM_HIP(ctx, hipMemset(ctx->d_stamps + 40 + 3 * 8192, 0, 2048 * 96 * sizeof(uint32_t)));
     return RM_OK;
 }
 

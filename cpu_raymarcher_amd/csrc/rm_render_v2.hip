@@ -59,7 +59,8 @@ using namespace rmd;
 #ifdef RM_STAMPS
 #define RM_T0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
     const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();                                                          \
-    if (lane == 0 && P.stamps) atomicMin(&P.stamps[6], t_start_);
+    if (lane == 0 && P.stamps) atomicMin(&P.stamps[6], t_start_);                                                                  \
+    if (lane == 0 && P.stamps && blockIdx.x * 4 + (threadIdx.x >> 6) < 8192) P.stamps[40 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t_start_;
 #define RM_T(i)                                                  \
     {                                                            \
         const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
@@ -75,6 +76,7 @@ using namespace rmd;
         const unsigned long long rel_ = __builtin_amdgcn_s_memrealtime() - (first_ < t_start_ ? first_ : t_start_); \
         unsigned long long b_ = rel_ / 6400ull;  /* 100 MHz: 64 us */                  \
         atomicAdd(&P.stamps[8 + (b_ > 31 ? 31 : b_)], 1ull);                            \
+        if (blockIdx.x * 4 + (threadIdx.x >> 6) < 8192) P.stamps[40 + 8192 + blockIdx.x * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); \
     }
 #else
 #define RM_T0()
@@ -836,6 +838,9 @@ template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef RM_STAMPS  // diagnostic builds: per-wave times (rm_debug_read_wave_times): kernel entry here, wave-loop start and end in RM_T0 / RM_TEND
+    if (lane == 0 && P.stamps && blockIdx.x * 4 + wave < 8192) P.stamps[40 + 2 * 8192 + blockIdx.x * 4 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     {   // staged once per persistent workgroup, at the places lds_layout() names
         const LdsLayout lay = lds_layout<ACCEL, LDS, REL>(P);
@@ -918,6 +923,9 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
     };
 
     RM_T0()
+#ifdef RM_STAMPS_LOG
+    int refill_k_ = 0;
+#endif
 #ifdef RM_COUNTS
     if (threadIdx.x < 32) rm_cnt_s[threadIdx.x] = 0;
     __syncthreads();
@@ -932,6 +940,12 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         const int n_idle = __popcll(idle);
         if (n_idle >= refill_at || n_idle == 64) {
             RM_CNT(1)
+#ifdef RM_STAMPS_LOG  // diagnostic: when does this wave begin its k-th batch?  (rm_debug_read_batch_log, scripts/batch_timeline.py)
+            if (lane == 0 && P.stamps && blockIdx.x * 4 + wave < 2048 && refill_k_ < 96)
+                reinterpret_cast<unsigned int *>(P.stamps + 40 + 3 * 8192)[(blockIdx.x * 4 + wave) * 96 + refill_k_] =
+                    static_cast<unsigned int>(__builtin_amdgcn_s_memrealtime());
+            refill_k_ += 1;
+#endif
             const RmRenderParams C = cold_params();
             TileQueue Q;
             Q.counters = C.tile_counters;
@@ -950,7 +964,20 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
             const bool want_tile = !no_more && qpos >= Q.item_px;
             const bool want_static = want_tile && static_j < C.static_per_wave;
             unsigned int claim = 0;
+#ifdef RM_STAMPS_CLAIM  // diagnostic: the queue atomic's round trip, waited for at once (the product overlaps it with the stores)
+            if (want_tile && !want_static) {
+                const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long tc1 = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0 && P.stamps) {
+                    atomicAdd(&P.stamps[38], tc1 - tc0);
+                    atomicAdd(&P.stamps[39], 1ull);
+                }
+            }
+#else
             if (want_tile && !want_static && lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
+#endif
             if (phase == PH_DONE && have_pixel) {
                 store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
                 have_pixel = false;

@@ -322,6 +322,13 @@ RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 /* Diagnostic builds only (make EXTRA=-DRM_COUNTS): reads and clears the execution counts of sixteen events of the
  * v2 wave loop (scripts/counts.py) or of the v1 octree kernels (scripts/counts_v1.py) -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
 RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
+/* Diagnostic builds only (make EXTRA=-DRM_STAMPS): start and end time (100 MHz ticks) of the first 8192 waves of the last
+ * v2 launch -- out[w] start of the wave loop, out[8192 + w] end, out[16384 + w] kernel entry, 0 where no wave ran
+ * (scripts/tail_hist.py). */
+RM_API int rm_debug_read_wave_times(rm_ctx *ctx, uint64_t *out24576);
+/* Diagnostic builds only (EXTRA="-DRM_STAMPS -DRM_STAMPS_LOG"): low 32 bits of the 100 MHz clock at the start of the first 96
+ * batches of the first 2048 waves of the last v2 launches, out[wave * 96 + k]; 0 = no such batch (scripts/batch_timeline.py). */
+RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
 
 /* Kernel-variant knobs for measurement; unknown keys or values are RM_E_INVALID.  They NEVER change results
  * (tests/test_gpu_parity.py renders every combination and compares the bytes).

@@ -127,6 +127,22 @@ def test_error_codes_without_a_device(rm):
         ctx.set_option("tile_w", 12)
     ctx.set_option("tile_w", 16)
     assert ctx.get_option("tile_w") == 16
+    # the round-2 knobs: defaults, accepted values, rejected values, unknown keys
+    assert (ctx.get_option("oct_lean"), ctx.get_option("v1_block"), ctx.get_option("v1_lists"), ctx.get_option("lpt")) == (1, 64, 1, 1)
+    for bad in (0, 32, 96, 512):
+        with pytest.raises(rm.RmError):
+            ctx.set_option("v1_block", bad)
+    for good in (128, 256, 64):
+        ctx.set_option("v1_block", good)
+        assert ctx.get_option("v1_block") == good
+    ctx.set_option("oct_lean", 0)
+    assert ctx.get_option("oct_lean") == 0
+    ctx.set_option("oct_lean", 7)  # any non-zero value switches it on
+    assert ctx.get_option("oct_lean") == 1
+    with pytest.raises(rm.RmError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(rm.RmError):
+        ctx.get_option("no_such_option")
 
 
 def test_camera_class_mirrors_reference(rm):

@@ -105,6 +105,7 @@ SIGNATURES = {
     "rm_reduce_counters": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics)]),
     "rm_reduce_counters_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.POINTER(rm_diagnostics), _VP]),
     "rm_reduce_counters_enqueue": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
+    "rm_render_attach_diagnostics": (C.c_int, [_VP, _VP]),
     "rm_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rm_selftest_hypot": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "rm_selftest_fastdiv": (C.c_int, [_VP, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]),
@@ -150,6 +151,8 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("RM_HIP_LIB") and not hasattr(L, name):
+                continue  # A/B measurements against an OLDER build of the library (scripts/kbench.py): newer entry points are absent there
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -163,17 +163,30 @@ class Context:
         return dist, cnt
 
     # ---- render ---------------------------------------------------------------------
-    def render_tile(self, job, depth, normal, sdf, iters, rgba=None, shader=0):
+    def _attach_diag(self, diag):
+        """rm_render_attach_diagnostics for the render call that follows: `diag` is a CUDA tensor of 32 bytes that
+        receives (total_sdf, total_iters, max_sdf | min_sdf << 32, pad) of the pixels that call renders (decode_acc)."""
+        if diag is None:
+            return
+        if not (_is_torch(diag) and diag.is_cuda and diag.is_contiguous() and diag.numel() * diag.element_size() >= 32):
+            raise ValueError("diag must be a contiguous CUDA tensor of 32 bytes")
+        self._same_device(dict(diag=diag))
+        N.check(self._h, N.lib().rm_render_attach_diagnostics(self._h, _ptr(diag)))
+
+    def render_tile(self, job, depth, normal, sdf, iters, rgba=None, shader=0, diag=None):
         """Host numpy buffers -> rm_render_tile (+ rm_shade when rgba is given); torch CUDA
-        tensors -> rm_render_tile_device on torch's current stream (fused shade)."""
+        tensors -> rm_render_tile_device on torch's current stream (fused shade; `diag`: fused diagnostics)."""
         npx = max(0, job.y_end - job.y_start) * max(0, job.width)
         bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
-        if _check_buffers(npx, bufs):
+        if _check_buffers(npx, bufs) or (diag is not None and all(b is None for b in bufs.values())):
             self._same_device(bufs)
+            self._attach_diag(diag)
             N.check(self._h, N.lib().rm_render_tile_device(
                 self._h, C.byref(job), int(shader), _ptr(depth), _ptr(normal), _ptr(sdf), _ptr(iters),
                 _ptr(rgba), _current_stream_ptr()))
             return
+        if diag is not None:
+            raise ValueError("fused diagnostics need device buffers")
         if depth is None or normal is None or sdf is None or iters is None:
             raise ValueError("the host entry point needs all four G-buffers")
         N.check(self._h, N.lib().rm_render_tile(self._h, C.byref(job), _ptr(depth), _ptr(normal),
@@ -187,7 +200,7 @@ class Context:
             if b is not None and _is_torch(b) and b.is_cuda and b.device.index != self.device:
                 raise ValueError("%s buffer is on cuda:%s, the context on cuda:%d" % (name, b.device.index, self.device))
 
-    def render_stripes(self, job, stripe_rows, n_parts, part, depth, normal, sdf, iters, rgba=None, shader=0):
+    def render_stripes(self, job, stripe_rows, n_parts, part, depth, normal, sdf, iters, rgba=None, shader=0, diag=None):
         """One launch for every stripe of `part` (rm_render_stripes_device); device buffers only."""
         rows = N.lib().rm_stripe_rows(job.y_start, job.y_end, int(stripe_rows), int(n_parts), int(part))
         if rows < 0:
@@ -195,11 +208,12 @@ class Context:
         bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
         _check_buffers(rows * max(0, job.width), bufs, need_device=True)
         self._same_device(bufs)
+        self._attach_diag(diag)
         N.check(self._h, N.lib().rm_render_stripes_device(
             self._h, C.byref(job), int(shader), int(stripe_rows), int(n_parts), int(part), _ptr(depth), _ptr(normal),
             _ptr(sdf), _ptr(iters), _ptr(rgba), _current_stream_ptr()))
 
-    def render_stripe_list(self, job, stripe_rows, stripe_ids, depth, normal, sdf, iters, rgba=None, shader=0):
+    def render_stripe_list(self, job, stripe_rows, stripe_ids, depth, normal, sdf, iters, rgba=None, shader=0, diag=None):
         """One launch for the listed stripes (strictly increasing ids; rm_render_stripe_list_device), packed in list
         order; device buffers only.  Serves any deal of stripes to ranks (deal_stripes)."""
         ids = np.ascontiguousarray(stripe_ids, dtype=np.int32)
@@ -208,6 +222,7 @@ class Context:
         bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)
         _check_buffers(max(0, rows) * max(0, job.width), bufs, need_device=True)
         self._same_device(bufs)
+        self._attach_diag(diag)
         N.check(self._h, N.lib().rm_render_stripe_list_device(
             self._h, C.byref(job), int(shader), int(stripe_rows), _ptr(ids), len(ids), _ptr(depth), _ptr(normal),
             _ptr(sdf), _ptr(iters), _ptr(rgba), _current_stream_ptr()))

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rm_raymarch.h"
+#include "rm_diag.h"
 #include "rm_kernels.h"
 #include "rm_scene_host.h"
 
@@ -82,7 +83,7 @@ struct rm_ctx {
     int64_t opt_nn = 2;  // per-cell nearest-candidate lists for the all-primitive fallback: 0 off, 1 on, 2 auto (scenes of
                          // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
     int64_t opt_blocks_per_cu = 4;  // persistent workgroups per launch and CU (a frame alone: 4 beats 5, 2.02 against 2.07 ms)
-    int64_t opt_lds_kb = 32;        // v2: LDS budget per workgroup the launcher trims the hit lists to (32: five per CU, 40: four)
+    int64_t opt_lds_kb = 0;         // v2: LDS budget per workgroup the launcher trims the hit lists to (0: as many workgroups per CU as the kernel's registers allow; 32: five per CU, 40: four)
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
     int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
@@ -116,6 +117,8 @@ struct rm_ctx {
         RmOctFrameNode *dev = nullptr;
         size_t nodes = 0;
         std::vector<std::pair<hipStream_t, hipEvent_t>> users;
+        hipStream_t builder = nullptr;  // the stream oct_frame_table_kernel ran on ...
+        hipEvent_t built = nullptr;     // ... and the event recorded right behind it: a launch on ANY OTHER stream waits for it
     };
     static constexpr int kOctFrameSlots = 32;
     OctFrameSlot oct_frames[kOctFrameSlots];
@@ -136,6 +139,12 @@ struct rm_ctx {
     unsigned int *d_counters = nullptr;  // ring of 1024 x 8 queue heads: a launch owns its slot until 1023 later launches
                                          // have been enqueued (frames in flight on several streams each need their own)
     unsigned int counter_slot = 0;
+    // Fused diagnostics (rm_diag.h): a ring of accumulator blocks, one per launch in flight like the queue heads above;
+    // zeroed once here, left zeroed by every launch's last wave.  diag_next: rm_render_attach_diagnostics, one-shot.
+    static constexpr unsigned kDiagBlocks = 1024;
+    RmDiagBlock *d_diag_blocks = nullptr;
+    unsigned int diag_slot = 0;
+    void *diag_next = nullptr;
     unsigned long long *d_stamps = nullptr;  // diagnostic build only
     int num_cus = 256;
 };
@@ -166,10 +175,27 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
                 oct_slot = &ctx->oct_frames[k];
                 ctx->oct_frame_cur = k;
             }
+        // A table found here may still be under construction on the stream that first saw this camera position (frames
+        // in flight share one table): a reader on another stream orders itself behind the builder (the `users`
+        // events only made the next WRITER wait for the readers, never a reader for the writer).
+        bool seen = false;  // a stream that has read this table before is already ordered behind the builder
+        if (oct_slot)
+            for (auto &u : oct_slot->users) seen = seen || u.first == stream;
+        if (oct_slot && oct_slot->builder != stream && !seen) {
+            if (oct_slot->built) {
+                if (hipStreamWaitEvent(stream, oct_slot->built, 0) != hipSuccess) (void)hipStreamSynchronize(oct_slot->builder);
+            } else {
+                (void)hipStreamSynchronize(oct_slot->builder);  // no event could be created when it was built
+            }
+        }
         if (!oct_slot) {  // a new camera position: the oldest table is rewritten once its readers are done
             const int k = static_cast<int>(ctx->oct_frame_next++ % rm_ctx::kOctFrameSlots);
             rm_ctx::OctFrameSlot &sl = ctx->oct_frames[k];
-            for (auto &u : sl.users) (void)hipEventSynchronize(u.second);
+            for (auto &u : sl.users) {
+                (void)hipEventSynchronize(u.second);
+                (void)hipEventDestroy(u.second);
+            }
+            sl.users.clear();  // `seen` above is about THIS table, not the one the slot held before
             sl.valid = false;
             if (sl.nodes < n) {
                 (void)hipFree(sl.dev);
@@ -182,6 +208,9 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
                 for (int a = 0; a < 3; ++a) sl.origin[a] = p.origin_d[a];
                 sl.gen = ctx->scene_gen;
                 sl.valid = true;
+                sl.builder = stream;
+                if (!sl.built && hipEventCreateWithFlags(&sl.built, hipEventDisableTiming) != hipSuccess) sl.built = nullptr;
+                if (!sl.built || hipEventRecord(sl.built, stream) != hipSuccess) (void)hipStreamSynchronize(stream);  // built before anyone else can look
                 oct_slot = &sl;
                 ctx->oct_frame_cur = k;
             }
@@ -212,6 +241,18 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
             p.lpt_cost_out = ctx->d_lpt_cost + slot * per_slot;
             p.lpt_perm_out = ctx->d_lpt_perm + slot * per_slot;
         }
+    }
+    // Fused diagnostics (rm_render_attach_diagnostics; one-shot).  v2 launches always get an accumulator block: their last
+    // wave also re-zeroes the launch's tile-queue heads.  A launch without pixels runs no kernel: neutral elements then.
+    p.diag_out = static_cast<RmDiagDevice *>(ctx->diag_next);
+    ctx->diag_next = nullptr;
+    p.diag_block = nullptr;
+    const bool empty = p.local_rows <= 0 || p.width <= 0;
+    if (!empty && ctx->d_diag_blocks && (p.diag_out || (p.variant == 2 && p.algorithm == 0)))
+        p.diag_block = ctx->d_diag_blocks + (ctx->diag_slot++ % rm_ctx::kDiagBlocks);
+    if (p.diag_out && empty) {
+        const hipError_t ei = rm_launch_reduce_init(p.diag_out, stream);
+        if (ei != hipSuccess) return ei;
     }
     const hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
     if (oct_slot) {  // this stream now reads the table: whoever rewrites it waits for this launch
@@ -612,6 +653,9 @@ int rm_create(int device, rm_ctx **out) {
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 1024 * 8 * sizeof(unsigned int));  // every launch leaves its heads zeroed (rm_diag.h)
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag_blocks), rm_ctx::kDiagBlocks * sizeof(RmDiagBlock));
+        if (e == hipSuccess) e = hipMemset(ctx->d_diag_blocks, 0, rm_ctx::kDiagBlocks * sizeof(RmDiagBlock));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), (40 + 3 * 8192 + 2048 * 48) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(ctx->d_stamps, 0, (40 + 3 * 8192 + 2048 * 48) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(ctx->d_stamps + 6, 0xFF, sizeof(unsigned long long));
@@ -638,6 +682,7 @@ void rm_destroy(rm_ctx *ctx) {
         (void)hipFree(ctx->scratch);
         (void)hipFree(ctx->d_diag);
         (void)hipFree(ctx->d_counters);
+        (void)hipFree(ctx->d_diag_blocks);
         (void)hipFree(ctx->d_stamps);
         for (auto &t : ctx->tables) (void)hipFree(t.dev);
         (void)hipFree(ctx->d_lpt_cost);
@@ -647,6 +692,7 @@ void rm_destroy(rm_ctx *ctx) {
         for (auto &sl : ctx->oct_frames) {
             (void)hipFree(sl.dev);
             for (auto &u : sl.users) (void)hipEventDestroy(u.second);
+            if (sl.built) (void)hipEventDestroy(sl.built);
         }
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
@@ -806,6 +852,14 @@ int rm_render_tile_device(rm_ctx *ctx, const rm_job *job, int32_t shader, void *
     p.rgba = static_cast<uint8_t *>(d_rgba);
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, launch_render(ctx, p, static_cast<hipStream_t>(stream)));
+    return RM_OK;
+}
+
+int rm_render_attach_diagnostics(rm_ctx *ctx, void *d_acc) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    if (d_acc && (reinterpret_cast<uintptr_t>(d_acc) & 7)) return fail(ctx, RM_E_INVALID, "the accumulator must be 8-byte aligned");
+    ctx->diag_next = d_acc;
     return RM_OK;
 }
 
@@ -1260,7 +1314,7 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         return RM_OK;
     }
     if (!std::strcmp(key, "lds_kb")) {
-        if (value < 16 || value > 64) return fail(ctx, RM_E_INVALID, "lds_kb must be in [16, 64]");
+        if (value != 0 && (value < 16 || value > 64)) return fail(ctx, RM_E_INVALID, "lds_kb must be 0 (auto) or in [16, 64]");
         ctx->opt_lds_kb = value;
         return RM_OK;
     }

@@ -42,10 +42,44 @@ __device__ unsigned long long *rm_cnt_g;
 #include "rm_bvh_list.h"
 #include "rm_program.h"
 #include "rm_kernels.h"
+#include "rm_diag.h"
 
 namespace {
 
 using namespace rmd;
+
+// Fused diagnostics of the one-ray-per-lane kernels (rm_diag.h): a wave stores its 64 pixels once, at its end; the four
+// totals of the wave are formed with LDS atomics (lanes outside the frame contribute nothing; eight slots, lane & 7: 64
+// lanes on one address would be 64 serial read-modify-writes) and flushed by the wave.  Reached by EVERY lane of every wave
+// of the launch (no early return above it), all 64 lanes active.  Out of line, plain arguments: the lean octree kernel
+// lives on exactly 64 VGPRs, and inlined this epilogue cost it two spills.
+__device__ __attribute__((noinline)) static void v1_diag_flush(RmDiagBlock *blk, RmDiagDevice *out, bool has_pixel, uint32_t c16, uint32_t i16) {
+    __shared__ unsigned int v1_diag_s[4][4][8];
+    const int lane = static_cast<int>(__lane_id());
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    unsigned int(*w)[8] = v1_diag_s[wave];
+    if (lane < 8) w[0][lane] = w[1][lane] = w[2][lane] = w[3][lane] = 0;  // (one wave's LDS operations execute in order)
+    if (has_pixel) {
+        const int k = lane & 7;
+        atomicAdd(&w[0][k], c16);
+        atomicAdd(&w[1][k], i16);
+        atomicMax(&w[2][k], c16);
+        atomicMax(&w[3][k], 0xFFFFFFFFu - c16);
+    }
+    unsigned int ts = 0, ti = 0, mx = 0, mi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ts += w[0][k];
+        ti += w[1][k];
+        mx = w[2][k] > mx ? w[2][k] : mx;
+        mi = w[3][k] > mi ? w[3][k] : mi;
+    }
+    const unsigned int wpw = blockDim.x >> 6;
+    diag_flush_wave<true>(blk, out, nullptr, ts, ti, mx, mi, blockIdx.x * wpw + static_cast<unsigned int>(wave), gridDim.x * wpw, lane);
+}
+__device__ __forceinline__ void v1_diag_epilogue(const RmRenderParams &P, bool has_pixel, uint32_t c16, uint32_t i16) {
+    if (P.diag_block) v1_diag_flush(P.diag_block, P.diag_out, has_pixel, c16, i16);
+}
 
 // ------------------------------------------------------------------ Scene.getDistance
 
@@ -695,8 +729,9 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     if (threadIdx.x == 0) rm_cnt_g = P.stamps;
     __syncthreads();
 #endif
-    if (x >= P.width || row >= P.local_rows) return;
-    RM_CNT1(14)
+    // (no early return: every wave takes part in the diagnostics flush at the end; a lane outside the frame starts finished)
+    const bool in_frame = x < P.width && row < P.local_rows;
+    if (in_frame) RM_CNT1(14)
     const int y = row_to_y(P, row);
     const Ray ray = make_ray(P, x, y);
     // 1 / direction (octree.ts:200) and, per axis, the byte offset inside RmOctNode of the face the ray leaves through
@@ -716,7 +751,7 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     // iterations (<= 100) in the low half, the SDF evaluations in the high half, where `+=` wraps exactly as the Uint16Array
     // store would (raymarcher.ts:103-106).  The trip counter of the march loop rides above the phase (phase in bits 0-2).
     uint32_t counters = 0;
-    int phase = PH_MARCH;  // | steps << 3
+    int phase = in_frame ? PH_MARCH : PH_DONE;  // | steps << 3
     double t = 0.0, d0 = 0.0;
     float nx = 0.f, ny = 0.f, nz = 0.f;
     const void *const nodes = P.oct;
@@ -861,7 +896,8 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
             }
         }
     }
-    store_pixel(P, static_cast<size_t>(row) * P.width + x, t, nx, ny, nz, counters >> 16, counters & 0xFFFFu);
+    if (in_frame) store_pixel(P, static_cast<size_t>(row) * P.width + x, t, nx, ny, nz, counters >> 16, counters & 0xFFFFu);
+    v1_diag_epilogue(P, in_frame, counters >> 16, counters & 0xFFFFu);
 }
 
 template <int ACCEL, bool OTHER, int GEN>
@@ -879,7 +915,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     if (threadIdx.x == 0) rm_cnt_g = P.stamps;
     __syncthreads();
 #endif
-    if (x >= P.width || row >= rows) return;
+    const bool in_frame = x < P.width && row < rows;  // (no early return: the diagnostics flush at the end takes every wave)
+    uint16_t c16 = 0, i16 = 0;
+    if (in_frame) {
     RM_CNT1(14)
     const int y = row_to_y(P, row);
     const size_t idx = static_cast<size_t>(row) * P.width + x;
@@ -909,8 +947,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     uint8_t nb[3];
     normal_and_store<ACCEL, GEN>(P, ray, depth, count, nb);
     const uint8_t db = u8clamp(depth);
-    const uint16_t c16 = static_cast<uint16_t>(count & 0xFFFFu);  // Uint16Array += wraps
-    const uint16_t i16 = static_cast<uint16_t>(iters & 0xFFFFu);
+    c16 = static_cast<uint16_t>(count & 0xFFFFu);  // Uint16Array += wraps
+    i16 = static_cast<uint16_t>(iters & 0xFFFFu);
     if (P.depth) P.depth[idx] = db;
     if (P.normal) {
         P.normal[3 * idx] = nb[0];
@@ -920,6 +958,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     if (P.sdf) P.sdf[idx] = c16;
     if (P.iters) P.iters[idx] = i16;
     if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light_d);
+    }
+    v1_diag_epilogue(P, in_frame, c16, i16);
 }
 
 #ifndef RM_LENGTH_SQRT  // scene-independent kernels exist once (this file is compiled a second time with -DRM_LENGTH_SQRT)

@@ -49,6 +49,7 @@ __shared__ unsigned int rm_cnt_s[32];
 
 #include "rm_bvh_list.h"  // after RM_CNT: the diagnostic build counts the list scans too
 #include "rm_kernels.h"
+#include "rm_diag.h"
 
 namespace {
 
@@ -86,6 +87,23 @@ using namespace rmd;
 
 enum Phase : int { PH_MARCH = 0, PH_N0 = 1, PH_N1 = 2, PH_N2 = 3, PH_N3 = 4, PH_DONE = 5 };
 
+// Fused diagnostics (rm_diag.h): a wave's running totals live in LDS, not in registers -- the wave loop has none to spare.
+// Every pixel store adds the two counters AS STORED (Uint16Array wrap included) with LDS atomics; the wave flushes once, at
+// its end.  Eight slots per wave (lane & 7), structure of arrays: 64 lanes on ONE address are 64 serial read-modify-writes
+// per instruction, four instructions per batch, and the LDS pipeline of the CU stands still meanwhile (measured at six waves
+// per SIMD: 932 -> 748 frames/s); eight addresses in eight banks are eight.
+struct WaveDiag {
+    unsigned long long sdf[8], iters[8];
+    unsigned int mx[8], mn_inv[8];
+};
+__device__ __forceinline__ void wave_diag_add(WaveDiag *w, int lane, uint32_t count, uint32_t iters) {
+    const unsigned int c16 = count & 0xFFFFu, i16 = iters & 0xFFFFu;
+    const int k = lane & 7;
+    atomicAdd(&w->sdf[k], static_cast<unsigned long long>(c16));
+    atomicAdd(&w->iters[k], static_cast<unsigned long long>(i16));
+    atomicMax(&w->mx[k], c16);
+    atomicMax(&w->mn_inv[k], 0xFFFFFFFFu - c16);
+}
 
 // Wave-wide minimum of a binary32 value with DPP row operations (no LDS traffic; the
 // ds_bpermute form of __shfl_xor cost 18 LDS round trips per fallback ray).  Every lane of the
@@ -419,7 +437,9 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
             const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
             in_root = true;
-            if (NRM) stable = box_answer_is_stable(root.lo, root.hi, q);
+            // (RM_NRM_DELTA's margin assumes half an ulp of a coordinate below 2^-21: |coordinate| < 16)
+            if (NRM) stable = box_answer_is_stable(root.lo, root.hi, q) &&
+                              __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)), __builtin_fabsf(q.z)) < 16.0f;
             const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
             const int ccnt = static_cast<int>(cell & 0xFFu);
             if (ccnt == 255) walk_tree = true;  // crowded cell: the tree walk below
@@ -824,20 +844,22 @@ __device__ __forceinline__ RmRenderParams cold_params() {
 }
 
 template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
-// 96 VGPRs without spills (since the Phong pow left the kernel): five waves per SIMD when the LDS footprint allows
-// (the REL instantiations keep six more doubles' worth of addressing live in the slab tests: at five waves they spill
-// VGPRs to scratch -- and gave wrong pixels with it, non-deterministically, in the build that first did -- so they are
-// compiled for four waves per SIMD; the launcher only picks them where the LDS budget leaves room, i.e. small scenes)
-// (likewise the vec3.length = sqrt(x*x + y*y + z*z) build: the compiler's full-range IEEE sqrt needs a register more than the
-// budget of five waves has)
-#ifdef RM_LENGTH_SQRT
-#define RM_V2_WAVES(REL) 4
-#else
-#define RM_V2_WAVES(REL) ((REL) ? 4 : 5)
-#endif
-__global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const RmRenderParams P) {
+// Round 3: 80 VGPRs without a spill and without scratch in every instantiation, vec3.length = sqrt build included: six
+// waves per SIMD (tests/test_build_invariants.py holds all of them to that).  Round 2 needed 96 (five waves; the REL and sqrt
+// builds spilled at five and ran at four); what changed is the lane state (see "lane state" below), the wave index as an
+// SGPR, and -amdgpu-inline-max-bb (Makefile).
+#define RM_V2_WAVES 6
+__global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ WaveDiag wave_diag[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform by construction: an SGPR, not a VGPR held for the whole kernel
+    if (lane < 8) {  // (LDS operations of one wave execute in order: no barrier between this and the wave's own atomics)
+        wave_diag[wave].sdf[lane] = 0;
+        wave_diag[wave].iters[lane] = 0;
+        wave_diag[wave].mx[lane] = 0;
+        wave_diag[wave].mn_inv[lane] = 0;
+    }
 #ifdef RM_STAMPS  // diagnostic builds: per-wave times (rm_debug_read_wave_times): kernel entry here, wave-loop start and end in RM_T0 / RM_TEND
     if (lane == 0 && P.stamps && blockIdx.x * 4 + wave < 8192) P.stamps[40 + 2 * 8192 + blockIdx.x * 4 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -878,13 +900,13 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
             __syncthreads();
         }
     }
-    const size_t off = lds_layout<ACCEL, LDS, REL>(P).end;
-    RayList L;
-    L.cap = P.list_cap;
-    L.cnt = 0;
-    L.live = 0;
-    L.cur_pos = 0;
-    L.col = reinterpret_cast<uint16_t *>(smem + off) + (static_cast<size_t>(wave) * L.cap) * 64 + lane;
+    const int list_cap = P.list_cap;
+    // this lane's column of the wave's hit-leaf lists (entry e at [e * 64]).  Formed where it is used, from parameters loaded
+    // there: a loop-invariant address would be hoisted into a register that lives for the whole kernel.
+    auto list_column = [&](const RmRenderParams &C) {
+        const uint32_t end = C.lds_off[9];
+        return reinterpret_cast<uint16_t *>(smem + end) + (static_cast<uint32_t>(wave) * static_cast<uint32_t>(C.list_cap)) * 64u + static_cast<uint32_t>(lane);
+    };
     const int item_px = P.item_px;
     // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
     int home = P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7);
@@ -896,30 +918,77 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
     int static_j = 0;
     unsigned int item_iters = 0;  // cost feedback for the next frame's longest-first order: wave-loop iterations spent on the current item
 
-    // ---- lane state ------------------------------------------------------------------------
-    Ray ray;  // set by the first refill (every lane starts idle)
-    ray.o = {0.f, 0.f, 0.f};
-    ray.d = {0.f, 0.f, -1.f};
-    ray.od[0] = ray.od[1] = ray.od[2] = 0.0;
-    RayInv ri;
-    if (ACCEL == 2) ri = make_ray_inv(ray);
-    uint32_t count = 0, iters = 0;
-    int phase = PH_DONE;
-    bool have_pixel = false;
-    int px = 0, prow = 0;  // pixel column, tile-local row of the lane's pixel
-    int loopi = 0;
-    double t = RM_MAX_DIST, d0 = 0.0;  // t: distance marched; after the march it is the returned depth
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    Interval cur;
-    cur.tEnter = 0.0;
-    cur.tExit = 0.0;
-    cur.ord = -1;
-    bool haveCur = false;
+    // ---- lane state (round 3: 21 registers instead of ~44; registers decide this kernel's occupancy) ----------------
+    //  * nothing wave-uniform: the ray origin is rebuilt from freshly loaded parameters where a section needs it
+    //    (a `Ray` assigned under a divergent branch kept its nine origin words in VGPRs);
+    //  * the march state {cur.tEnter, cur.tExit, cur.ord} and the normal state {d0, (nx, ny), nz} share sA / sB / sC: a
+    //    ray is in one phase or the other (bvh.ts:204-240 against raymarcher.ts:123-135);
+    //  * both Uint16Array counters in one word (iterations <= 100 in the low half; the SDF evaluations in the high half,
+    //    where `+=` wraps as the store would), the loop trip counter and the ray's flags beside the phase, the list
+    //    bookkeeping in one word, the pixel as its buffer index.
+    enum : int { ST_PHASE = 7, ST_TRIP_SHIFT = 3, ST_TRIP_MASK = 127 << 3, ST_HAVECUR = 1 << 10, ST_PAR_SHIFT = 11, ST_PAR_MASK = 7 << 11,
+                 ST_PIXEL = 1 << 14,
+                 ST_LIVE_SHIFT = 15, ST_POS_SHIFT = 22, ST_OVF = 1 << 29, ST_LIST_MASK = (0x3FFF << 15) | (1 << 29) };  // hit-leaf list: live (7 bits), cur_pos (7), overflow
+    Vec3f rd = {0.f, 0.f, -1.f};              // ray direction
+    double inv0 = 0.0, inv1 = 0.0, inv2 = 0.0;  // 1 / direction (BVH slab tests)
+    double t = RM_MAX_DIST;                   // distance marched; after the march it is the returned depth
+    double sA = 0.0, sB = 0.0;                // march: cur.tEnter, cur.tExit | normal: d0, (nx, ny) as two binary32 words
+    int sC = -1;                              // march: cur.ord | normal: nz
+    uint32_t counters = 0;                    // sdfEval << 16 | iterations
+    uint32_t pidx = 0;                        // tile-local pixel index (row * width + column; the launcher checks it fits)
+    int st = PH_DONE;                         // phase | trips << 3 | flags | hit-leaf list bookkeeping
 
-    // march finished with distance `dist_total` (raymarcher.ts:91-102)
+    auto ray_of = [&](const RmRenderParams &C) {
+        Ray r;
+        r.d = rd;
+        r.o = {C.origin[0], C.origin[1], C.origin[2]};
+        r.od[0] = C.origin_d[0];
+        r.od[1] = C.origin_d[1];
+        r.od[2] = C.origin_d[2];
+        return r;
+    };
+    auto inv_of = [&]() {
+        RayInv ri;
+        ri.inv[0] = inv0;
+        ri.inv[1] = inv1;
+        ri.inv[2] = inv2;
+        ri.par[0] = (st & (1 << ST_PAR_SHIFT)) != 0;
+        ri.par[1] = (st & (2 << ST_PAR_SHIFT)) != 0;
+        ri.par[2] = (st & (4 << ST_PAR_SHIFT)) != 0;
+        ri.any_par = (st & ST_PAR_MASK) != 0;
+        return ri;
+    };
+    auto list_of = [&](const RmRenderParams &C) {
+        RayList L;
+        L.col = list_column(C);
+        L.cap = list_cap;
+        L.live = (st >> ST_LIVE_SHIFT) & 127;
+        L.cur_pos = (st >> ST_POS_SHIFT) & 127;
+        L.cnt = (st & ST_OVF) ? list_cap + 1 : L.live;  // only `cnt <= cap` is ever asked after the prologue
+        return L;
+    };
+    auto keep_list = [&](const RayList &L) {
+        // (list_cap <= 64: live <= 64 and cur_pos <= 63 whenever the list is complete; beyond that only the overflow bit is read)
+        st = (st & ~ST_LIST_MASK) | ((L.live & 127) << ST_LIVE_SHIFT) | ((L.cur_pos & 127) << ST_POS_SHIFT) | (L.cnt > list_cap ? ST_OVF : 0);
+    };
+    auto set_phase = [&](int ph) { st = (st & ~ST_PHASE) | ph; };
+    auto nrm_x = [&]() { return __int_as_float(__double2loint(sB)); };
+    auto nrm_y = [&]() { return __int_as_float(__double2hiint(sB)); };
+    auto set_normal = [&](float nx, float ny, float nz) {
+        sB = __hiloint2double(__float_as_int(ny), __float_as_int(nx));
+        sC = __float_as_int(nz);
+    };
+    // march finished with distance `dist_total` (raymarcher.ts:91-102).  No normal is formed when depth >= MAX_DIST
+    // (raymarcher.ts:97-99): the store applies that very test to t, so nothing is zeroed here.
     auto finish_march = [&](double dist_total) {
         t = dist_total;
-        phase = (t >= RM_MAX_DIST) ? PH_DONE : PH_N0;
+        set_phase((t >= RM_MAX_DIST) ? PH_DONE : PH_N0);
+    };
+    auto store_mine = [&](const RmRenderParams &C) {
+        const bool miss = t >= RM_MAX_DIST;
+        const float nx = miss ? 0.f : nrm_x(), ny = miss ? 0.f : nrm_y(), nz = miss ? 0.f : __int_as_float(sC);
+        store_pixel(C, static_cast<size_t>(pidx), t, nx, ny, nz, counters >> 16, counters & 0xFFFFu);
+        if (C.diag_out) wave_diag_add(&wave_diag[wave], lane, counters >> 16, counters & 0xFFFFu);
     };
 
     RM_T0()
@@ -936,7 +1005,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         item_iters += 1;
         // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
         // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
-        const unsigned long long idle = __ballot(phase == PH_DONE);
+        const unsigned long long idle = __ballot((st & ST_PHASE) == PH_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle >= refill_at || n_idle == 64) {
             RM_CNT(1)
@@ -978,9 +1047,9 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
 #else
             if (want_tile && !want_static && lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
 #endif
-            if (phase == PH_DONE && have_pixel) {
-                store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
-                have_pixel = false;
+            if ((st & (ST_PHASE | ST_PIXEL)) == (PH_DONE | ST_PIXEL)) {
+                store_mine(C);
+                st &= ~ST_PIXEL;
             }
             if (want_tile && C.lpt_cost_out && tile_col >= 0) {  // the item just finished: what it cost.  Its place in its queue
                 // follows from its tile: the queue is the one it was pulled from (= home), the row slot inverts queue_entry
@@ -1007,61 +1076,77 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
                 const int remaining = Q.item_px - qpos;
                 const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(idle >> 32),
                                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned int>(idle), 0u));
-                const bool take = phase == PH_DONE && rank < remaining;
+                const bool take = (st & ST_PHASE) == PH_DONE && rank < remaining;
                 bool in_frame = false;  // this lane received a pixel inside the frame
                 // a whole batch from one 64-pixel sub-tile (the normal case): its hit leaves come from the bundle cull
                 const bool whole_batch = ACCEL == 2 && C.bvh_leaf_count > 0 && n_idle == 64 && (qpos & 63) == 0;
                 const int batch_sub = qpos >> 6;
+                Ray ray = ray_of(C);
+                RayInv ri = inv_of();
                 if (take) {
                     const int n = qpos + rank;  // pixel n of the tile, in 64-pixel sub-tile order
                     const int sub = n >> 6, l = n & 63;
-                    px = (tile_col << C.tile_w_log2) + (l & (Q.tile_w - 1));
-                    prow = (tile_row << C.tile_h_log2) + sub * (64 >> C.tile_w_log2) + (l >> C.tile_w_log2);
+                    const int px = (tile_col << C.tile_w_log2) + (l & (Q.tile_w - 1));
+                    const int prow = (tile_row << C.tile_h_log2) + sub * (64 >> C.tile_w_log2) + (l >> C.tile_w_log2);
                     if (px < C.width && prow < C.local_rows) {
                         in_frame = true;
-                        have_pixel = true;
+                        pidx = static_cast<uint32_t>(prow) * static_cast<uint32_t>(C.width) + static_cast<uint32_t>(px);
                         ray = make_ray(C, px, row_to_y(C, prow));
-                        count = 0;
-                        iters = 0;
-                        loopi = 0;
+                        rd = ray.d;
+                        counters = 0;
                         t = 0.0;
-                        nx = ny = nz = 0.f;
-                        phase = PH_MARCH;
-                        if (ACCEL == 2) ri = make_ray_inv(ray);
+                        st = PH_MARCH | ST_PIXEL;  // no trips yet, no interval, no parallel axis
+                        if (ACCEL == 2) {
+                            ri = make_ray_inv(ray);
+                            inv0 = ri.inv[0];
+                            inv1 = ri.inv[1];
+                            inv2 = ri.inv[2];
+                            st |= ((ri.par[0] ? 1 : 0) | (ri.par[1] ? 2 : 0) | (ri.par[2] ? 4 : 0)) << ST_PAR_SHIFT;
+                        }
                     }
                 }
                 if (ACCEL == 2) {
 #ifdef RM_STAMPS
                     const unsigned long long t_pr0 = __builtin_amdgcn_s_memtime();
 #endif
+                    RayList L = list_of(C);
+                    Interval cur;
+                    cur.tEnter = sA;
+                    cur.tExit = sB;
+                    cur.ord = sC;
+                    bool hc = false;
                     if (whole_batch) {
                         const int x0 = tile_col << C.tile_w_log2;
                         const int r0 = (tile_row << C.tile_h_log2) + batch_sub * (64 >> C.tile_w_log2);
                         const Bundle B = make_bundle(C, x0, x0 + Q.tile_w - 1, row_to_y(C, r0),
                                                      row_to_y(C, r0 + (64 >> C.tile_w_log2) - 1));
-                        const bool hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane);
-                        if (in_frame) haveCur = hc;
+                        hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane);
                     } else if (in_frame) {
                         RM_CNT(15)
-                        haveCur = bvh_prologue<REL>(scene_view<ACCEL, LDS, REL>(C, smem), ray, ri, L, cur);
+                        hc = bvh_prologue<REL>(scene_view<ACCEL, LDS, REL>(C, smem), ray, ri, L, cur);
                     }
 #ifdef RM_STAMPS
                     t_acc_[5] += __builtin_amdgcn_s_memtime() - t_pr0;
                     t_prev_ += __builtin_amdgcn_s_memtime() - t_pr0;
 #endif
-                    if (in_frame && !haveCur) {  // bvh.ts:190-192: exactly MAX_DIST, zero normal
-                        t = RM_MAX_DIST;
-                        phase = PH_DONE;
+                    if (in_frame) {
+                        keep_list(L);
+                        if (hc) {
+                            sA = cur.tEnter;
+                            sB = cur.tExit;
+                            sC = cur.ord;
+                            st |= ST_HAVECUR;
+                        } else {  // bvh.ts:190-192: exactly MAX_DIST, zero normal
+                            t = RM_MAX_DIST;
+                            set_phase(PH_DONE);
+                        }
                     }
                 }
                 qpos += n_idle < remaining ? n_idle : remaining;
             }
         }
-        if (no_more && !__any(phase != PH_DONE)) {
-            if (have_pixel) {
-                const RmRenderParams C = cold_params();
-                store_pixel(C, static_cast<size_t>(prow) * C.width + px, t, nx, ny, nz, count, iters);
-            }
+        if (no_more && !__any((st & ST_PHASE) != PH_DONE)) {
+            if (st & ST_PIXEL) store_mine(cold_params());
             break;
         }
         RM_T(0)
@@ -1071,29 +1156,42 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         // lives in SGPRs across the wave loop.
         const RmRenderParams CA = cold_params();
         const SceneView S = scene_view<ACCEL, LDS, REL>(CA, smem);
+        const Ray ray = ray_of(CA);
         bool need = false;
         Vec3f q = {0.f, 0.f, 0.f};
         int onode = -1;
-        if (phase == PH_MARCH) {
+        if ((st & ST_PHASE) == PH_MARCH) {
             for (;;) {
-                if (loopi >= RM_MAX_STEPS) {  // loop exhausted: return totalDist
+                if ((st & ST_TRIP_MASK) >= (RM_MAX_STEPS << ST_TRIP_SHIFT)) {  // loop exhausted: return totalDist
                     finish_march(t);
                     break;
                 }
-                loopi++;
+                st += 1 << ST_TRIP_SHIFT;
                 RM_CNT(2)
                 const Vec3f p = point_at(ray, t);
                 if (ACCEL == 2) {
                     // BVH.onRayMarchStep (bvh.ts:204-240)
                     double skip = 0.0;
-                    bool terminate = !haveCur;
+                    bool terminate = !(st & ST_HAVECUR);
                     if (!terminate) {
-                        if (t < cur.tEnter) skip = cur.tEnter - t;
-                        else if (t > cur.tExit) {
-                            const Interval prev = cur;
-                            haveCur = bvh_next<REL>(S, ray, ri, L, prev.tEnter, prev.ord, cur);
-                            if (!haveCur) terminate = true;
-                            else if (cur.tEnter > t) skip = cur.tEnter - t;
+                        if (t < sA) skip = sA - t;
+                        else if (t > sB) {
+                            RayList L = list_of(CA);
+                            Interval cur;
+                            cur.tEnter = sA;
+                            cur.tExit = sB;
+                            cur.ord = sC;
+                            const bool hc = bvh_next<REL>(S, ray, inv_of(), L, sA, sC, cur);
+                            keep_list(L);
+                            if (!hc) {
+                                st &= ~ST_HAVECUR;
+                                terminate = true;
+                            } else {
+                                sA = cur.tEnter;
+                                sB = cur.tExit;
+                                sC = cur.ord;
+                                if (sA > t) skip = sA - t;
+                            }
                         }
                     }
                     if (terminate) {  // -1: return MAX_DIST
@@ -1131,15 +1229,18 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         // march distance any more; then all of them take ONE round for the hit point (n0_go) and, where the evaluation
         // allows it, get the three offset distances from the same sphere without three more rounds (section N below).
         bool n0_go = true;
-        if (ACCEL == 2) n0_go = !__any(need) || __popcll(__ballot(phase == PH_N0)) >= CA.n0_batch;
-        if (phase >= PH_N0 && phase <= PH_N3 && (phase != PH_N0 || n0_go)) {  // raymarcher.ts:123-132 sample points
-            RM_CNT(14)
-            q = point_at(ray, t);  // hitPosition (raymarcher.ts:94-95), recomputed: 3 VGPRs fewer
-            if (phase == PH_N1) q.x = to_f32(static_cast<double>(q.x) - 0.01);
-            if (phase == PH_N2) q.y = to_f32(static_cast<double>(q.y) - 0.01);
-            if (phase == PH_N3) q.z = to_f32(static_cast<double>(q.z) - 0.01);
-            if (ACCEL == 1) onode = oct_find(S, q);
-            need = true;
+        if (ACCEL == 2) n0_go = !__any(need) || __popcll(__ballot((st & ST_PHASE) == PH_N0)) >= CA.n0_batch;
+        {
+            const int ph = st & ST_PHASE;
+            if (ph >= PH_N0 && ph <= PH_N3 && (ph != PH_N0 || n0_go)) {  // raymarcher.ts:123-132 sample points
+                RM_CNT(14)
+                q = point_at(ray, t);  // hitPosition (raymarcher.ts:94-95), recomputed: 3 VGPRs fewer
+                if (ph == PH_N1) q.x = to_f32(static_cast<double>(q.x) - 0.01);
+                if (ph == PH_N2) q.y = to_f32(static_cast<double>(q.y) - 0.01);
+                if (ph == PH_N3) q.z = to_f32(static_cast<double>(q.z) - 0.01);
+                if (ACCEL == 1) onode = oct_find(S, q);
+                need = true;
+            }
         }
         RM_T(1)
         if (!__any(need)) continue;  // every live ray just finished: go and refill
@@ -1151,6 +1252,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         const bool coop = CB.coop != 0, filter = CB.filter != 0;
         const bool use_grid = ACCEL == 2 && CB.use_grid != 0;
         double dist;
+        uint32_t evaluated = 0;  // primitives this round counts (raymarcher.ts:117-119)
         NormalAux aux;
         aux.ok = false;
         aux.k1 = 0;
@@ -1159,42 +1261,45 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
         if (ACCEL == 2) {
 #ifdef RM_STAMPS
             unsigned long long fbc = 0;
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, count, lane, coop, filter, use_grid, &fbc, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, count, lane, coop, filter, use_grid, &fbc);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, &fbc, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, &fbc);
             t_acc_[4] += fbc;
             t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
 #else
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, count, lane, coop, filter, use_grid, nullptr, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, count, lane, coop, filter, use_grid, nullptr);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, nullptr, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, nullptr);
 #endif
         }
-        else if (ACCEL == 1) dist = need ? oct_distance_lane(SB, onode, q, count, filter) : RM_MAX_DIST;
+        else if (ACCEL == 1) dist = need ? oct_distance_lane(SB, onode, q, evaluated, filter) : RM_MAX_DIST;
         else {
             dist = all_prims_wave(SB, need, q, lane, coop, filter);
-            if (need) count += static_cast<uint32_t>(SB.n_prims);
+            if (need) evaluated = static_cast<uint32_t>(SB.n_prims);
         }
+        counters += evaluated << 16;  // Uint16Array += : the carry out of the upper half is the wrap
 
         RM_T(2)
         // ---- C: consume -------------------------------------------------------------------------
-        const bool fuse = ACCEL == 2 && need && phase == PH_N0 && aux.ok;
+        const bool fuse = ACCEL == 2 && need && (st & ST_PHASE) == PH_N0 && aux.ok;
         if (need) {
-            if (phase == PH_MARCH) {
+            const int ph = st & ST_PHASE;
+            if (ph == PH_MARCH) {
                 t += dist;
-                iters += 1;
+                counters += 1;
                 if (dist < RM_EPSILON || t > RM_MAX_DIST) finish_march(t);
-            } else if (phase == PH_N0) {
-                d0 = dist;
-                phase = PH_N1;
-            } else if (phase == PH_N1) {
-                nx = to_f32(d0 - dist);
-                phase = PH_N2;
-            } else if (phase == PH_N2) {
-                ny = to_f32(d0 - dist);
-                phase = PH_N3;
+            } else if (ph == PH_N0) {
+                sA = dist;  // d0
+                set_phase(PH_N1);
+            } else if (ph == PH_N1) {
+                sB = __hiloint2double(__double2hiint(sB), __float_as_int(to_f32(sA - dist)));  // nx
+                set_phase(PH_N2);
+            } else if (ph == PH_N2) {
+                sB = __hiloint2double(__float_as_int(to_f32(sA - dist)), __double2loint(sB));  // ny
+                set_phase(PH_N3);
             } else {
-                nz = to_f32(d0 - dist);
+                float nx = nrm_x(), ny = nrm_y(), nz = to_f32(sA - dist);
                 normalize3(nx, ny, nz);
-                phase = PH_DONE;
+                set_normal(nx, ny, nz);
+                set_phase(PH_DONE);
             }
         }
         // ---- N: the three offset samples of getNormal (raymarcher.ts:126-132) from the sphere that gave d0.  The leaf
@@ -1215,18 +1320,37 @@ __global__ __launch_bounds__(256, RM_V2_WAVES(REL)) void render_kernel_v2(const 
                 const double e1 = sphere_sdf_fast(s1, r1, qx), e2 = sphere_sdf_fast(s1, r1, qy), e3 = sphere_sdf_fast(s1, r1, qz);
                 const double emax = __builtin_fmax(__builtin_fmax(e1, e2), e3);
                 if (aux.lb2 - RM_NRM_DELTA > f32_upper_bound(emax)) {
-                    count += 3u * aux.found;
-                    nx = to_f32(d0 - __builtin_fmin(e1, RM_MAX_DIST));  // Math.min(sdf, closestDistance = 10)
-                    ny = to_f32(d0 - __builtin_fmin(e2, RM_MAX_DIST));
-                    nz = to_f32(d0 - __builtin_fmin(e3, RM_MAX_DIST));
+                    counters += (3u * aux.found) << 16;
+                    float nx = to_f32(sA - __builtin_fmin(e1, RM_MAX_DIST));  // Math.min(sdf, closestDistance = 10)
+                    float ny = to_f32(sA - __builtin_fmin(e2, RM_MAX_DIST));
+                    float nz = to_f32(sA - __builtin_fmin(e3, RM_MAX_DIST));
                     normalize3(nx, ny, nz);
-                    phase = PH_DONE;
+                    set_normal(nx, ny, nz);
+                    set_phase(PH_DONE);
                 }
             }
         }
         RM_T(3)
     }
     RM_TEND()
+    {   // the wave's totals to the launch's accumulator block; the launch's last wave publishes the result and re-zeroes
+        // the block and the tile-queue heads (rm_diag.h).  All 64 lanes are active here (the loop's exit is wave-uniform).
+        const RmRenderParams C = cold_params();
+        if (C.diag_block) {
+            const WaveDiag *w = &wave_diag[wave];
+            unsigned long long ts = 0, ti = 0;
+            unsigned int mx = 0, mi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // (every lane reads the same eight slots: broadcasts)
+                ts += w->sdf[k];
+                ti += w->iters[k];
+                mx = w->mx[k] > mx ? w->mx[k] : mx;
+                mi = w->mn_inv[k] > mi ? w->mn_inv[k] : mi;
+            }
+            diag_flush_wave(C.diag_block, C.diag_out, C.tile_counters, ts, ti, mx, mi, blockIdx.x * 4u + static_cast<unsigned int>(wave),
+                            gridDim.x * 4u, lane);
+        }
+    }
 #ifdef RM_COUNTS
     __syncthreads();
     if (threadIdx.x < 32 && P.stamps) atomicAdd(&P.stamps[8 + threadIdx.x], static_cast<unsigned long long>(rm_cnt_s[threadIdx.x]));
@@ -1319,6 +1443,7 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
     if (kernel_name) *kernel_name = "";
     if (rows <= 0 || p.width <= 0) return hipSuccess;
     if (!p.tile_counters) return hipErrorInvalidValue;
+    if (p.leaf_order) p.bvh_prim_count = 0;  // the leaf lists are the identity (spheres stored in leaf order): nothing reads them, nothing is staged
     if (p.item_px != 64 && p.item_px != 128 && p.item_px != 256) p.item_px = 64;
     if (p.item_px < p.tile_w) p.item_px = p.tile_w;
     const int tw = p.tile_w, th = p.item_px / tw;
@@ -1340,21 +1465,33 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
     const size_t scene_bytes = scene_lds_bytes(p);
     // stage the scene in LDS when it leaves room for >= 2 workgroups per CU (160 KB LDS)
     const bool lds = p.nodes_in_lds != 0 && scene_bytes + list_bytes + 16 <= 64 * 1024;
-    // LDS budget per workgroup: 32 KB lets five workgroups (five waves per SIMD, what 96 VGPRs allow) share a CU's
-    // 160 KB, 40 KB four.  The per-ray hit lists give way down to 16 entries to reach a budget (rays that hit more
-    // leaves take the tree-walk form of bvh_next, as they do beyond any cap); origin-relative node boxes (48 B per
-    // node) ride along when they fit the same budget.
+    // LDS budget per workgroup.  The kernels hold 80 VGPRs: six waves per SIMD = six four-wave workgroups per CU, if six
+    // fit the CU's 160 KB of LDS.  LDS is handed out in granules of 1 280 bytes (measured in round 3: a workgroup of
+    // 32 096 bytes, dynamic + static, no longer ran five to a CU -- 26 granules = 33 280 -- and the frame rate with frames in
+    // flight fell 5 %; hipOccupancyMaxActiveBlocksPerMultiprocessor does not model it), so the budgets are whole granules:
+    // 26 880 bytes for six, 32 000 for five, 40 960 for four.  The per-ray hit lists give way down to 12 entries to reach a
+    // budget (rays that hit more leaves take the tree-walk form of bvh_next, as they do beyond any cap); origin-relative
+    // node boxes (48 B per node) ride along when they fit the same budget.  Option `lds_kb` (> 0) names a budget itself.
     bool rel = false;
     const size_t rel_bytes = static_cast<size_t>(p.bvh_nodes) * 48;
     if (lds && p.accel == 2) {
-        auto fits = [&](size_t extra, int cap, size_t budget) { return scene_bytes + extra + static_cast<size_t>(4) * cap * 128 + 32 <= budget; };
-        auto trim = [&](size_t extra, size_t budget) {  // largest cap <= list_cap (>= 16, or list_cap itself if smaller) that fits; 0 if none
+        constexpr size_t kLdsPerCu = 160 * 1024, kGranule = 1280, kStatic = sizeof(WaveDiag) * 4;
+        auto budget_for = [&](size_t bytes) { return bytes / kGranule * kGranule - kStatic; };  // dynamic bytes of a workgroup
+        auto fits = [&](size_t extra, int cap, size_t budget) { return scene_bytes + extra + static_cast<size_t>(4) * cap * 128 + 16 <= budget; };
+        auto trim = [&](size_t extra, size_t budget) {  // largest cap <= list_cap (>= 12, or list_cap itself if smaller) that fits; 0 if none
             int cap = p.list_cap;
-            while (cap > 16 && !fits(extra, cap, budget)) cap -= 8;
+            while (cap > 12 && !fits(extra, cap, budget)) cap -= 1;
             return fits(extra, cap, budget) ? cap : 0;
         };
-        const size_t budgets[2] = {static_cast<size_t>(p.lds_budget_kb > 0 ? p.lds_budget_kb : 32) * 1024, 40 * 1024};
-        for (int b = 0; b < 2; ++b) {
+        size_t budgets[4];
+        int nb = 0;
+        if (p.lds_budget_kb > 0) budgets[nb++] = budget_for(static_cast<size_t>(p.lds_budget_kb) * 1024);
+        else {
+            budgets[nb++] = budget_for(kLdsPerCu / RM_V2_WAVES);
+            budgets[nb++] = budget_for(kLdsPerCu / 5);
+        }
+        budgets[nb++] = budget_for(kLdsPerCu / 4);
+        for (int b = 0; b < nb; ++b) {
             int cap = p.rel_boxes ? trim(rel_bytes + 16, budgets[b]) : 0;
             if (cap > 0) rel = true;
             else cap = trim(0, budgets[b]);
@@ -1386,7 +1523,10 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
         p.static_per_wave = static_cast<int32_t>(rounds);
         p.queue_base = static_cast<int32_t>(rounds * per_round);
     }
-    hipError_t e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
+    // the tile-queue heads are zero: a launch's last wave leaves them so (rm_diag.h).  Without an accumulator block
+    // (a caller below the API layer) they are cleared here.
+    hipError_t e = hipSuccess;
+    if (!p.diag_block) e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     // longest-first item order (option `lpt`): the api layer hands in the cost / permutation buffers and their stride
     p.lpt_perm = nullptr;

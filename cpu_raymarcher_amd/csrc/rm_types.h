@@ -103,7 +103,10 @@ struct RmInstr {
 #define RM_MAX_DIST 10.0
 #define RM_EPSILON 0.001
 
-// Kernel parameters (passed by value; < 256 B).
+struct RmDiagBlock;   // rm_diag.h
+struct RmDiagDevice;  // rm_kernels.h
+
+// Kernel parameters (passed by value).
 struct RmRenderParams {
     int32_t width, height, y_start, y_end;
     float rot[9];     // mat3.fromMat4(camera rotation), column-major
@@ -172,7 +175,7 @@ struct RmRenderParams {
     // v2: the first `static_per_wave` items of every wave are assigned without an atomic (wave g takes entries
     // g + total_waves * j of the interleaved queues); the queues hand out the rest, starting at queue_base
     int32_t static_per_wave, queue_base, total_waves;
-    int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = 32 KB: five workgroups per CU)
+    int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = six workgroups per CU, then five, then four)
     int32_t static_share;  // percent of the shortest queue assigned statically (option; 0 = all dynamic)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
@@ -203,4 +206,9 @@ struct RmRenderParams {
     uint16_t *sdf;
     uint16_t *iters;
     uint8_t *rgba;
+    // Fused diagnostics (rm_diag.h; main.ts:528-548): the launch's accumulator block (from a ring in rm_api.cpp; all zero
+    // before and after the launch) and where the launch's last wave writes the 32-byte result (null: no diagnostics).
+    // v2 launches always carry a block: the last wave also re-zeroes the launch's tile-queue heads.
+    RmDiagBlock *diag_block;
+    RmDiagDevice *diag_out;
 };

@@ -135,15 +135,17 @@ class Raymarcher:
         return 10
 
     def runRaymarcher(self, scene, depthBuffer, normalBuffer, SDFevaluationBuffer, iterationsBuffer,
-                      width, height, time=0.0, yStart=0, yEnd=None, shadedBuffer=None, shader="normal"):
-        """raymarcher.ts:46-57.  shadedBuffer/shader are an extension: fused ShadingModel.shade."""
+                      width, height, time=0.0, yStart=0, yEnd=None, shadedBuffer=None, shader="normal", diagnostics=None):
+        """raymarcher.ts:46-57.  shadedBuffer/shader are an extension: fused ShadingModel.shade; so is `diagnostics`
+        (device buffers only): a CUDA tensor of 32 bytes that receives the sums / max / min of main.ts:528-548 over the
+        rendered rows from the render kernel itself (rm_render_attach_diagnostics; read with Context.decode_acc)."""
         if yEnd is None:
             yEnd = height
         job = _job(scene, width, height, time, yStart, yEnd, self.algorithm,
                    getattr(self, "overshootFactor", None), getattr(self, "stepSize", None))
         sh = N.lib().rm_shader_from_string(str(shader).encode())
         scene.ctx.render_tile(job, depthBuffer, normalBuffer, SDFevaluationBuffer, iterationsBuffer,
-                              rgba=shadedBuffer, shader=sh)
+                              rgba=shadedBuffer, shader=sh, diag=diagnostics)
 
 
 class SphereTracer(Raymarcher):  # cpu_algorithms/sphereTracer.ts

@@ -290,6 +290,16 @@ RM_API int rm_reduce_counters_device(rm_ctx *ctx, const void *d_sdf, const void 
 RM_API int rm_reduce_counters_enqueue(rm_ctx *ctx, const void *d_sdf, const void *d_iters, int64_t n,
                                       void *d_acc, void *stream);
 
+/* The same diagnostics WITHOUT a second pass over the counters: the next render call on this context
+ * (rm_render_tile_device, rm_render_stripes_device or rm_render_stripe_list_device) also leaves, in device memory
+ * `d_acc` (32 bytes, 8-byte aligned, the layout of rm_reduce_counters_enqueue), the sum / max / min of the sdfEval
+ * values and the sum of the iteration values of exactly the pixels it renders -- as stored, Uint16Array wrap included
+ * (raymarcher.ts:79-80,119; main.ts:534-543).  The render kernel accumulates them from the registers it stores the
+ * counters from and its last wave writes the result: no initialisation of d_acc, no further launch, and the counter
+ * buffers themselves may be NULL.  A call that renders no pixel writes the neutral elements (sums 0, max 0, min
+ * UINT32_MAX).  One-shot: consumed by the next render call whether it succeeds or not; d_acc = NULL cancels. */
+RM_API int rm_render_attach_diagnostics(rm_ctx *ctx, void *d_acc);
+
 /* ---- tile partition (main.ts:444-450) ------------------------------------------- */
 
 /* rows of worker i of n: [min(i*r, H), min((i+1)*r, H)) with r = ceil(H / n) */

@@ -31,6 +31,7 @@ def main():
     names = [a for a in sys.argv[1:] if "=" not in a] or ["C3"]
     kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     S = int(kv.pop("S", 12))
+    fused = int(kv.pop("fused", 1))  # diagnostics from the render kernel itself (rm_render_attach_diagnostics); 0: reduce kernels
     frames = int(kv.pop("frames", 96))
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
     dev = torch.device("cuda:0")
@@ -58,8 +59,8 @@ def main():
                      acc=torch.zeros(4, dtype=torch.int64, device=dev)) for _ in range(S)]
         tr = R.SphereTracer()
 
-        def render(b):
-            tr.runRaymarcher(sc, b["d"], b["n"], b["s"], b["i"], W, H, 0.0, shadedBuffer=b["r"], shader=wl["shader"])
+        def render(b, diag=None):
+            tr.runRaymarcher(sc, b["d"], b["n"], b["s"], b["i"], W, H, 0.0, shadedBuffer=b["r"], shader=wl["shader"], diagnostics=diag)
 
         b = sets[0]
         render(b)
@@ -90,8 +91,11 @@ def main():
             for f in range(n):
                 k = f % S
                 with torch.cuda.stream(streams[k]):
-                    render(sets[k])
-                    ctx.reduce_counters_enqueue(sets[k]["s"], sets[k]["i"], sets[k]["acc"])
+                    if fused:
+                        render(sets[k], sets[k]["acc"])
+                    else:
+                        render(sets[k])
+                        ctx.reduce_counters_enqueue(sets[k]["s"], sets[k]["i"], sets[k]["acc"])
         run(2 * S)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -101,6 +105,11 @@ def main():
         for k, v in saved.items():
             ctx.set_option(k, v)
         d = ctx.decode_acc(sets[0]["acc"])
+        chk = torch.zeros(4, dtype=torch.int64, device=dev)  # the fused diagnostics against the reduction kernels
+        ctx.reduce_counters_enqueue(sets[0]["s"], sets[0]["i"], chk)
+        torch.cuda.synchronize()
+        if ctx.decode_acc(chk) != d:
+            verdict += " DIAG MISMATCH %s vs %s" % (d, ctx.decode_acc(chk))
         print("%-9s %-16s alone %7.3f ms | %2d in flight %7.1f frames/s (%.3f ms) | avg sdf %.3f it %.3f | %s"
               % (name, verdict, alone, S, fps, 1e3 / fps, d["total_sdf"] / (W * H), d["total_iters"] / (W * H), kern), flush=True)
 

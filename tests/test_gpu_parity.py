@@ -96,13 +96,13 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, static=75), dict(kernel=2, static=95, item_px=64),
                      dict(kernel=2, nn=1, coop=0), dict(kernel=2, uniform=0), dict(kernel=2, uniform=0, list_cap=2),
                      dict(kernel=2, rel=0), dict(kernel=2, rel=0, uniform=0), dict(kernel=2, rel=1, list_cap=2),
-                     dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16),
+                     dict(kernel=2, item_px=256, tile_w=8, blocks_per_cu=2), dict(kernel=2, lds_kb=40), dict(kernel=2, lds_kb=16), dict(kernel=2, lds_kb=32),
                      dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0),
                      dict(kernel=2, n0_batch=1), dict(kernel=2, n0_batch=16, refill=24), dict(kernel=2, n0_batch=8, uniform=0, cull=0),
                      dict(kernel=2, lpt=0), dict(kernel=2, lpt=1), dict(kernel=2, lpt=1, item_px=64, tile_w=32),
                      dict(kernel=1, oct_lean=0), dict(kernel=1, oct_lean=0, v1_block=256, tile_w=16), dict(kernel=1, v1_block=128, tile_w=32)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
-                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=32, cull=1,
+                             hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=0, cull=1,
                              n0_batch=64, lpt=1, oct_lean=1, v1_block=64).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
@@ -276,6 +276,60 @@ def test_lean_octree_kernel_and_its_camera_tables(rm, oracle):
     ctx.close()
 
 
+def test_octree_camera_table_is_built_before_another_stream_reads_it(rm, oracle):
+    """the per-camera octree table is built on the stream of the FIRST launch that sees a camera
+    position; a launch with the same position on another stream must wait for that build (bench.py's C5 line keeps twelve
+    frames of one camera in flight).  Stream A is kept busy so that its table build is still queued when streams B and C
+    launch the same camera; every frame must equal the frame rendered alone."""
+    import torch
+    ctx = rm.Context(0)
+    sp = oracle.synthetic_spheres(10000)
+    W, H = 480, 270
+    dev = torch.device("cuda:0")
+    scene = rm.Scene("Octree", ctx=ctx)
+    scene.loadSpheres(sp[:, :3], sp[:, 3])
+    tracer = rm.SphereTracer()
+    yaws = [0.37 * k + 0.05 for k in range(6)]
+
+    def buffers(w=W, h=H):
+        return [torch.zeros(w * h, dtype=torch.uint8, device=dev), torch.zeros(3 * w * h, dtype=torch.uint8, device=dev),
+                torch.zeros(w * h, dtype=torch.int16, device=dev), torch.zeros(w * h, dtype=torch.int16, device=dev)]
+
+    def render(b, yaw, w=W, h=H):
+        scene.camera.setAngles(0.15, yaw)
+        tracer.runRaymarcher(scene, *b, w, h, 0.0)
+        assert "render_kernel_oct" in ctx.last_kernel(), ctx.last_kernel()
+
+    alone = []
+    for yaw in yaws:
+        b = buffers()
+        render(b, yaw)
+        torch.cuda.synchronize()
+        alone.append([v.clone() for v in b])
+    ctx.close()
+    # a fresh context: no table exists for any of these positions yet
+    ctx = rm.Context(0)
+    scene = rm.Scene("Octree", ctx=ctx)
+    scene.loadSpheres(sp[:, :3], sp[:, 3])
+    A, B, C = (torch.cuda.Stream(device=dev) for _ in range(3))
+    busy = buffers(1920, 1080)
+    sets = [[buffers() for _ in range(3)] for _ in yaws]
+    for k, yaw in enumerate(yaws):
+        with torch.cuda.stream(A):
+            render(busy, yaw + 0.011, 1920, 1080)  # ~1 ms of work in front of the table build
+            render(sets[k][0], yaw)               # builds the table for `yaw` on stream A
+        with torch.cuda.stream(B):
+            render(sets[k][1], yaw)               # same position, at once, on another stream
+        with torch.cuda.stream(C):
+            render(sets[k][2], yaw)
+    torch.cuda.synchronize()
+    for k in range(len(yaws)):
+        for s in range(3):
+            for a, b in zip(sets[k][s], alone[k]):
+                assert torch.equal(a, b), (k, s)
+    ctx.close()
+
+
 def test_static_tile_share_on_a_frame_large_enough_to_use_it(rm):
     """The statically assigned part of the tile queues only exists when a frame has more items than one round
     over all waves: 1920x1080 gives two rounds.  Every share must produce the same bytes."""
@@ -400,6 +454,136 @@ def test_many_primitives_fallback_and_u16_wrap(rm, gpu_ctx, oracle):
     assert_same(got, cpu_render(oracle, None, "BVH", 160, 90, (-0.2, 0.4), spheres=sp), "10k bvh")
     got = gpu_render(rm, gpu_ctx, None, "Octree", 320, 180, spheres=sp)
     assert_same(got, cpu_render(oracle, None, "Octree", 320, 180, spheres=sp), "10k octree")
+
+
+def _oracle_diag(want):
+    sdf, it = want[2].astype(np.int64), want[3].astype(np.int64)
+    if sdf.size == 0:
+        return {"total_sdf": 0, "total_iters": 0, "max_sdf": 0, "min_sdf": 0xFFFFFFFF}
+    return {"total_sdf": int(sdf.sum()), "total_iters": int(it.sum()), "max_sdf": int(sdf.max()), "min_sdf": int(sdf.min())}
+
+
+@pytest.mark.parametrize("case", [
+    dict(preset=3, accel="BVH", size=(301, 173), ang=(0.2, 0.5)),                      # v2 headline kernel, ragged tiles
+    dict(preset=3, accel="BVH", size=(301, 173), ang=(0.2, 0.5), opts=dict(refill=24, item_px=64, blocks_per_cu=1)),
+    dict(preset=3, accel="None", size=(200, 120)),                                     # v2 without acceleration
+    dict(preset=2, accel="BVH", size=(333, 97)),                                       # v1 (small scene)
+    dict(preset=3, accel="Octree", size=(250, 141), ang=(0.3, 0.7)),                   # lean octree kernel
+    dict(preset=3, accel="Octree", size=(250, 141), opts=dict(oct_lean=0, v1_block=256, tile_w=16)),  # four-wave v1 workgroups
+    dict(preset=9, accel="BVH", size=(160, 90)),                                       # boxes (GEN 1)
+    dict(preset=17, accel="BVH", size=(96, 64)),                                       # expression program (GEN 2)
+    dict(preset=3, accel="BVH", size=(150, 80), alg="adaptive-step-v2"),               # another marcher
+    dict(synthetic=10000, accel="None", size=(32, 32), rows=(15, 17)),                 # Uint16Array wrap: sums of the WRAPPED values
+    dict(preset=3, accel="BVH", size=(64, 48), rows=(20, 20)),                         # no pixel at all: neutral elements
+])
+def test_fused_diagnostics_equal_the_reduction(rm, oracle, case):
+    """rm_render_attach_diagnostics: the render kernels accumulate the diagnostics of main.ts:528-548 from the registers
+    they store the counters from.  Against the oracle's counters (sum / max / min over the very bytes it stores) and against
+    rm_reduce_counters on the buffers; also with the counter buffers absent, and twice in a row (the accumulator blocks
+    and the tile-queue heads are left zeroed by each launch's last wave)."""
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = rm.Context(0)
+    for k, v in case.get("opts", {}).items():
+        ctx.set_option(k, v)
+    W, H = case["size"]
+    y0, y1 = case.get("rows", (0, H))
+    sp = oracle.synthetic_spheres(case["synthetic"]) if "synthetic" in case else None
+    sc = rm.Scene(case["accel"], ctx=ctx)
+    if sp is not None:
+        sc.loadSpheres(sp[:, :3], sp[:, 3])
+    else:
+        sc.loadPreset(case["preset"])
+    sc.camera.setAngles(*case.get("ang", (0.0, 0.0)))
+    n = W * max(0, y1 - y0)
+    alg = case.get("alg", "sphere-tracer")
+    tracer = rm.createRaymarcher(alg, None, None)
+    want = cpu_render(oracle, case.get("preset"), case["accel"], W, H, case.get("ang", (0.0, 0.0)), rows=(y0, y1), spheres=sp, algorithm=alg)
+    wd = _oracle_diag(want)
+    for rep in range(2):
+        d = torch.zeros(max(1, n), dtype=torch.uint8, device=dev)
+        nr = torch.zeros(max(1, 3 * n), dtype=torch.uint8, device=dev)
+        s16 = torch.zeros(max(1, n), dtype=torch.int16, device=dev)
+        i16 = torch.zeros(max(1, n), dtype=torch.int16, device=dev)
+        acc = torch.full((4,), -1, dtype=torch.int64, device=dev)  # garbage: the kernel must write all of it
+        tracer.runRaymarcher(sc, d, nr, s16, i16, W, H, 0.0, y0, y1, diagnostics=acc)
+        torch.cuda.synchronize()
+        got = ctx.decode_acc(acc)
+        assert got == wd, (rep, got, wd)
+        if n:
+            red = ctx.reduce_counters(s16[:n], i16[:n])
+            assert {k: red[k] for k in wd} == wd
+            assert np.array_equal(s16[:n].cpu().numpy().view(np.uint16), want[2]) and np.array_equal(i16[:n].cpu().numpy().view(np.uint16), want[3])
+        # the counters need not be stored at all
+        acc2 = torch.full((4,), -1, dtype=torch.int64, device=dev)
+        rgba = torch.zeros(max(1, 4 * n), dtype=torch.uint8, device=dev)
+        tracer.runRaymarcher(sc, None, None, None, None, W, H, 0.0, y0, y1, shadedBuffer=rgba, shader="iteration-heatmap", diagnostics=acc2)
+        torch.cuda.synchronize()
+        assert ctx.decode_acc(acc2) == wd
+        if n:
+            assert np.array_equal(rgba[:4 * n].cpu().numpy(), oracle.shade("iteration-heatmap", *want, W, y1 - y0))
+    ctx.close()
+
+
+def test_fused_diagnostics_of_stripes_and_frames_in_flight(rm, oracle):
+    """The sharded entry points (one launch per rank's stripes, equal and weighted deals) and several frames in flight on
+    several streams, each with its own accumulator: every accumulator equals the reduction of that launch's own counters."""
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = rm.Context(0)
+    W, H, stripe, world = 320, 203, 7, 3
+    sc = rm.Scene("BVH", ctx=ctx)
+    sc.loadPreset(3)
+    sc.camera.setAngles(0.1, 0.4)
+    from cpu_raymarcher_amd import host
+    job = host._job(sc, W, H, 0.0, 0, H, "sphere-tracer", None, None)
+    total = {"total_sdf": 0, "total_iters": 0, "max_sdf": 0, "min_sdf": 0xFFFFFFFF}
+    from cpu_raymarcher_amd.context import deal_stripes
+    owner = deal_stripes(H, stripe, world, [500, 1000, 1300])
+    for part in range(world):
+        for mode in ("round-robin", "list"):
+            if mode == "round-robin":
+                rows = rm._native.lib().rm_stripe_rows(0, H, stripe, world, part)
+            else:
+                ids = [s_ for s_ in range(len(owner)) if owner[s_] == part]
+                rows = sum(min(H, (i + 1) * stripe) - i * stripe for i in ids)
+            s16 = torch.zeros(rows * W, dtype=torch.int16, device=dev)
+            i16 = torch.zeros(rows * W, dtype=torch.int16, device=dev)
+            acc = torch.full((4,), -1, dtype=torch.int64, device=dev)
+            if mode == "round-robin":
+                ctx.render_stripes(job, stripe, world, part, None, None, s16, i16, diag=acc)
+            else:
+                ctx.render_stripe_list(job, stripe, ids, None, None, s16, i16, diag=acc)
+            torch.cuda.synchronize()
+            red = ctx.reduce_counters(s16, i16)
+            got = ctx.decode_acc(acc)
+            assert got == {k: red[k] for k in got}, (part, mode)
+            if mode == "list":
+                total["total_sdf"] += got["total_sdf"]
+                total["total_iters"] += got["total_iters"]
+                total["max_sdf"] = max(total["max_sdf"], got["max_sdf"])
+                total["min_sdf"] = min(total["min_sdf"], got["min_sdf"])
+    assert total == _oracle_diag(cpu_render(oracle, 3, "BVH", W, H, (0.1, 0.4)))  # partial results combine exactly
+    # frames in flight: 4 streams x 3 rounds, different cameras, one accumulator per launch
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    tracer = rm.SphereTracer()
+    for k in ("blocks_per_cu", "item_px", "tile_w"):
+        ctx.set_option(k, {"blocks_per_cu": 1, "item_px": 256, "tile_w": 8}[k])
+    runs = []
+    for f in range(12):
+        with torch.cuda.stream(streams[f % 4]):
+            sc.camera.setAngles(0.05 * f, 0.3 * f)
+            s16 = torch.zeros(W * H, dtype=torch.int16, device=dev)
+            i16 = torch.zeros(W * H, dtype=torch.int16, device=dev)
+            acc = torch.full((4,), -1, dtype=torch.int64, device=dev)
+            tracer.runRaymarcher(sc, None, None, s16, i16, W, H, 0.0, diagnostics=acc)
+            runs.append((s16, i16, acc))
+    torch.cuda.synchronize()
+    for f, (s16, i16, acc) in enumerate(runs):
+        red = ctx.reduce_counters(s16, i16)
+        got = ctx.decode_acc(acc)
+        assert got == {k: red[k] for k in got}, f
+    ctx.close()
 
 
 def test_empty_scene_and_bad_inputs(rm, gpu_ctx, oracle):

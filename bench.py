@@ -7,8 +7,9 @@ one rank per GPU, RCCL through torch.distributed.)
 
 A step = one frame of BASELINE.json's metric workload (C3: Dense Sphere Grid, 125 spheres,
 3840x2160, sphere tracing + BVH, iteration-heatmap shader): render + fused shade into
-{depth, normal, sdfEval, iters, RGBA} resident in HBM, then the diagnostics reduction of
-main.ts:528-548 on the device.  At N > 1 the frame's rows are sharded over the ranks
+{depth, normal, sdfEval, iters, RGBA} resident in HBM, and the diagnostics of main.ts:528-548 (sum / max / min of the
+counters), which the render kernel accumulates while it stores the counters (rm_render_attach_diagnostics; `--diagnostics
+reduce` runs round 2's two reduction launches over the stored counters instead).  At N > 1 the frame's rows are sharded over the ranks
 (interleaved 16-row stripes, dealt by a weighted round-robin: rank 0 also reassembles the frame, so it renders a
 smaller share); every rank reduces the counters of its own rows, and one gather brings its RGBA rows and its
 32-byte partial diagnostics to rank 0, which rebuilds the frame and combines the partial sums with ONE native
@@ -27,8 +28,14 @@ Rank 0 prints ONE JSON line (contract in the task statement).  What each number 
                         is the mean duration of serial launches (HIP events on the launch stream); frac = achieved /
                         peak.  The overlapped figure (bytes x launches / wall time) is `achieved_in_flight`.
                         traffic = FETCH_SIZE + WRITE_SIZE per launch and valu = the instruction mix priced with the
-                        measured issue costs, both from profiles/r02/pmc_<workload>.json -- used only if that file was
+                        measured issue costs, both from profiles/r03/pmc_<workload>.json -- used only if that file was
                         measured on the kernel sources now in the tree (source hash) with the options of this run.
+  frames_verified       after the timed region every buffer set that was in flight (the last frame rendered into each of
+                        the S sets, with the in-flight options and the tail-ramp values of the timed burst) is hashed
+                        (SHA-256, all five buffers) against tests/golden/golden.json; the count of sets that match.  A
+                        mismatch makes the run fail.
+  host_enqueue_ms       host time this rank spent enqueueing one frame (render, gather, fan-in calls), mean over the
+                        timed region; at N > 1 one value per rank
   cpu_baseline          the reference's policy on this box's host cores: oracle/rm_oracle.js (the JS restatement; the
                         reference itself cannot run here) on node worker_threads, N = max(1, min(4, cores - 1)) workers,
                         contiguous ceil(H/N)-row tiles, whole frames after a warm-up (main.ts:318,444-449), plus the C
@@ -51,16 +58,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_PIXEL = 12  # depth 1 + normal 3 + sdfEval 2 + iters 2 + RGBA 4, ~0 read
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 WORKLOADS = {
     "C2": dict(name="C2: Grid of Spheres (9), 1920x1080, sphere-tracing + BVH, Phong shader",
-               preset=2, accel="BVH", width=1920, height=1080, shader="phong"),
+               preset=2, accel="BVH", width=1920, height=1080, shader="phong", golden="C2_grid_1080p_bvh_phong"),
     "C3": dict(name="C3: Dense Sphere Grid (125 spheres), 3840x2160, sphere-tracing + BVH, iteration-heatmap shader",
-               preset=3, accel="BVH", width=3840, height=2160, shader="iteration-heatmap"),
+               preset=3, accel="BVH", width=3840, height=2160, shader="iteration-heatmap", golden="C3_dense_4k_bvh_iterheat"),
     "C5": dict(name="C5: synthetic 10000 random spheres (splitmix64 0x5EED5EED), 3840x2160, sphere-tracing + Octree, "
                     "iteration-heatmap shader",
-               synthetic=10000, accel="Octree", width=3840, height=2160, shader="iteration-heatmap"),
+               synthetic=10000, accel="Octree", width=3840, height=2160, shader="iteration-heatmap",
+               golden="C5_random10k_4k_octree_iterheat"),
     # boxes / tori / rotated transforms (not BASELINE configs; same frame size as C3)
     "N3": dict(name="N3: Pyramid of Boxes (preset 9), 3840x2160, sphere-tracing + BVH, Phong shader",
                preset=9, accel="BVH", width=3840, height=2160, shader="phong"),
@@ -99,7 +107,7 @@ def kernel_source_hash():
 
 
 def load_pmc(workload, options):
-    """profiles/r02/pmc_<workload>.json (scripts/profile_r02.sh + scripts/make_pmc_json.py), or (None, reason)."""
+    """profiles/r03/pmc_<workload>.json (scripts/profile_r02.sh + scripts/make_pmc_json.py), or (None, reason)."""
     path = os.path.join(PROFILE_DIR, "pmc_%s.json" % workload)
     try:
         with open(path) as f:
@@ -212,6 +220,10 @@ def main():
                     help="N > 1: rank 0's stripe share relative to the other ranks' (1.0 = equal deal), or 'auto': measured "
                          "before the warm-up (rank 0's reassembly + an equal shard's render time, no collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--diagnostics", default="fused", choices=["fused", "reduce"],
+                    help="fused: the render kernel accumulates the diagnostics of main.ts:528-548 itself (rm_render_attach_diagnostics); "
+                         "reduce: two more launches per frame re-read the stored counters (round 2)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the SHA-256 check of the in-flight buffer sets after the timed region")
     ap.add_argument("--analytics-sweep", action="store_true",
                     help="rotate the camera by 0.015 rad of yaw per frame like the reference's Analytics view "
                          "(main.ts:438-441) and report the per-frame metric series (main.ts:550-566); N = 1 only")
@@ -251,28 +263,47 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll = dist
+    phase = ["setup", 0]  # what this rank was doing, for the message of a failing collective (fail() below)
+
+    def fail(exc):
+        """A collective that fails or times out must end the run with a message and a non-zero exit code inside the
+        driver's limit, not sit in a wait: rank, phase and frame to stderr, then leave without the interpreter's
+        teardown (which would wait for the process group again).  Never re-exec: this process has touched the GPU."""
+        sys.stderr.write("bench.py: rank %d of %d failed in phase '%s', frame %d: %s: %s\n"
+                         % (rank, world, phase[0], phase[1], type(exc).__name__, exc))
+        sys.stderr.flush()
+        os._exit(3)
+
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        # the watchdog of torch's NCCL / RCCL backend aborts the process when a collective exceeds the timeout
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        to = datetime.timedelta(seconds=int(os.environ.get("RM_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+        except Exception as e:  # noqa: BLE001
+            fail(e)
+    if world > 1 and backend != "nccl":
 
-            class _Done:
-                def wait(self):
-                    return True
+        class _Done:
+            def wait(self):
+                return True
 
-            class _HostStagedGather:  # same call shape as torch.distributed.gather on CUDA tensors
-                @staticmethod
-                def gather(tensor, gather_list=None, dst=0, async_op=False):
-                    torch.cuda.synchronize()
-                    src = tensor.cpu()
-                    out = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
-                    dist.gather(src, out, dst=dst)
-                    if rank == dst:
-                        for g, o in zip(gather_list, out):
-                            g.copy_(o)
-                    return _Done()
-            coll = _HostStagedGather
+        class _HostStagedGather:  # same call shape as torch.distributed.gather on CUDA tensors
+            @staticmethod
+            def gather(tensor, gather_list=None, dst=0, async_op=False):
+                torch.cuda.synchronize()
+                src = tensor.cpu()
+                out = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+                dist.gather(src, out, dst=dst)
+                if rank == dst:
+                    for g, o in zip(gather_list, out):
+                        g.copy_(o)
+                return _Done()
+        coll = _HostStagedGather
 
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
@@ -313,6 +344,7 @@ def main():
         scene.loadPrims(mixed_prims_as_triples(synthetic_mixed_prims(wl["mixed"]), R.make_transform))
     else:
         scene.loadPreset(wl["preset"])
+    fused = args.diagnostics == "fused"
     tracer = R.SphereTracer()
     u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)  # noqa: E731
     i16 = lambda n: torch.zeros(n, dtype=torch.int16, device=dev)  # noqa: E731
@@ -329,6 +361,7 @@ def main():
             sets.append(dict(depth=u8(W * H), normal=u8(3 * W * H), rgba=u8(4 * W * H), sdf=i16(W * H), iters=i16(W * H),
                              acc=torch.zeros(4, dtype=torch.int64, device=dev)))
         acc = sets[0]["acc"]
+        last_acc = [acc]
         frame_no = [0]
         series = []  # analytics sweep: one accumulator per frame, read after the timed region
 
@@ -346,16 +379,18 @@ def main():
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
+                a = b["acc"]
+                if args.analytics_sweep and timed:  # the per-frame metric series of main.ts:550-566: one accumulator per frame
+                    a = torch.zeros(4, dtype=torch.int64, device=dev)
+                    series.append((scene.camera.yaw, a))
                 tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0,
-                                     shadedBuffer=b["rgba"], shader=wl["shader"])
+                                     shadedBuffer=b["rgba"], shader=wl["shader"], diagnostics=a if fused else None)
                 if timed:
                     e1.record()
                     ev_pairs.append((e0, e1))
-                if args.analytics_sweep and timed:
-                    a = torch.zeros(4, dtype=torch.int64, device=dev)
+                if not fused:
                     ctx.reduce_counters_enqueue(b["sdf"], b["iters"], a)
-                    series.append((scene.camera.yaw, a))
-                ctx.reduce_counters_enqueue(b["sdf"], b["iters"], b["acc"])
+                last_acc[0] = a
 
         def finish():
             pass
@@ -389,7 +424,7 @@ def main():
                 cal_acc = torch.zeros(4, dtype=torch.int64, device=dev)
 
                 ra_extra = [None]  # the buffer set of the frame being enqueued: its rank-local sdfEval / iters
-                ra = D.gpu_render_all(ctx, scene, W, H, wl["shader"], lay0, rank, extra=lambda packed: ra_extra[0])
+                ra = D.gpu_render_all(ctx, scene, W, H, wl["shader"], lay0, rank, extra=lambda packed: ra_extra[0], diag_in_tail=fused)
 
                 def cal_frames(n, with_asm):
                     torch.cuda.synchronize()
@@ -400,8 +435,9 @@ def main():
                         with torch.cuda.stream(streams[k % S]):
                             ra_extra[0] = b
                             ra(b["p"])
-                            tail = b["p"][lay0.tail_offset:lay0.tail_offset + 32].view(torch.int64)
-                            ctx.reduce_counters_enqueue(b["sdf"][:cal_px], b["iters"][:cal_px], tail)
+                            if not fused:
+                                tail = b["p"][lay0.tail_offset:lay0.tail_offset + 32].view(torch.int64)
+                                ctx.reduce_counters_enqueue(b["sdf"][:cal_px], b["iters"][:cal_px], tail)
                             if with_asm:
                                 cal_asm.assemble(k, cal_acc)
                     torch.cuda.synchronize()
@@ -445,11 +481,12 @@ def main():
         def timed_render_rows(a, b, local, packed):
             timed_call(render_rows, a, b, local, packed)
 
-        render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank, extra=None if gather_counters else extra)
+        render_all = D.gpu_render_all(ctx, scene, W, H, wl["shader"], layout, rank, extra=None if gather_counters else extra,
+                                      diag_in_tail=fused and not gather_counters)
 
         def timed_render_all(packed):
             timed_call(render_all, packed)
-            if not gather_counters:  # this rank's partial diagnostics, into the tail that travels with the gather
+            if not gather_counters and not fused:  # this rank's partial diagnostics, into the tail that travels with the gather
                 c = extra(packed)
                 tail = packed[layout.tail_offset:layout.tail_offset + 32].view(torch.int64)
                 ctx.reduce_counters_enqueue(c["sdf"][:my_px], c["iters"][:my_px], tail)
@@ -503,29 +540,86 @@ def main():
     setup_frames = 0
     if S > args.warmup:
         setup_frames = S
-        for _ in range(S):
+        phase[0] = "set-up frames"
+        try:
+            for i in range(S):
+                phase[1] = i
+                step(False)
+            finish()
+            sync()
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                fail(e)
+            raise
+    host_enqueue = 0.0
+    try:
+        phase[0] = "warm-up"
+        for i in range(args.warmup):
+            phase[1] = i
             step(False)
         finish()
         sync()
-    for _ in range(args.warmup):
-        step(False)
-    finish()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if world == 1:
-            step(True, args.steps - 1 - i)
-        else:
-            step(True)
-    finish()
-    sync()
-    elapsed = time.perf_counter() - t0
+        phase[0] = "timed region"
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            phase[1] = i
+            h0 = time.perf_counter()
+            if world == 1:
+                step(True, args.steps - 1 - i)
+            else:
+                step(True)
+            host_enqueue += time.perf_counter() - h0
+        phase[0] = "drain of the timed region"
+        finish()
+        sync()
+        elapsed = time.perf_counter() - t0
+    except Exception as e:  # noqa: BLE001 -- a failed collective / launch: say where, leave non-zero (fail() does not return)
+        if world > 1:
+            fail(e)
+        raise
     apply_opts(True)
+    host_enqueue_ms = [1e3 * host_enqueue / max(1, args.steps)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        phase[0] = "all-reduce of the timings"
+        try:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            he = torch.tensor(host_enqueue_ms, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            hl = [torch.zeros_like(he) for _ in range(world)]
+            dist.all_gather(hl, he)
+            host_enqueue_ms = [float(x.item()) for x in hl]
+        except Exception as e:  # noqa: BLE001
+            fail(e)
     kernel_in_flight = ctx.last_kernel()
+
+    # The timed configuration checks itself: every buffer set that was in flight holds the last frame
+    # rendered into it -- with the in-flight options, and for the last sets the tail-ramp values -- and all five buffers of
+    # every set must hash to the committed golden fixtures of this workload (C = JS oracle agreement, tests/golden/).
+    frames_verified, verify_note = None, None
+    if world == 1 and not args.analytics_sweep and not args.no_verify and "golden" in wl:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            gold = json.load(f)[wl["golden"]]["sha256"]
+        used = min(S, frame_no[0])
+        frames_verified = 0
+        for k in range(used):
+            b = sets[k]
+            bad = [name for name in ("depth", "normal", "sdf", "iters", "rgba")
+                   if not (name == "rgba" and wl["shader"] == "phong")  # Math.pow: +-1 LSB contract, not hash-pinned
+                   and hashlib.sha256(b[name].cpu().numpy().tobytes()).hexdigest() != gold[name]]
+            if bad:
+                raise SystemExit("bench.py: buffer set %d of the timed region differs from the golden fixture %s in %s"
+                                 % (k, wl["golden"], ", ".join(bad)))
+            frames_verified += 1
+        verify_note = ("SHA-256 of depth, normal, sdfEval, iters%s of each of the %d buffer sets in flight against "
+                       "tests/golden/golden.json[%s]" % ("" if wl["shader"] == "phong" else ", RGBA", used, wl["golden"]))
+        # ... and the diagnostics the timed frames produced (fused: by the render kernel) against the fixture's
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            gd = json.load(f)[wl["golden"]].get("diagnostics")
+        for k in range(used):
+            dd = ctx.decode_acc(sets[k]["acc"])
+            if gd and any(dd[key] != gd[key] for key in ("total_sdf", "total_iters", "max_sdf", "min_sdf")):
+                raise SystemExit("bench.py: diagnostics of buffer set %d, %s, differ from the golden fixture's %s" % (k, dd, gd))
 
     # dominant kernel: the render kernel.  kern_ms_in_flight = mean launch duration inside the timed region (HIP events
     # on the launch stream; with S > 1 it spans the other frames' work too).
@@ -563,8 +657,9 @@ def main():
             t0 = time.perf_counter()
             for _ in range(n_ser):
                 tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0,
-                                     shadedBuffer=b["rgba"], shader=wl["shader"])
-                ctx.reduce_counters_enqueue(b["sdf"], b["iters"], b["acc"])
+                                     shadedBuffer=b["rgba"], shader=wl["shader"], diagnostics=b["acc"] if fused else None)
+                if not fused:
+                    ctx.reduce_counters_enqueue(b["sdf"], b["iters"], b["acc"])
             torch.cuda.synchronize()
             value_serial = n_ser / (time.perf_counter() - t0)
         apply_opts(True)
@@ -572,7 +667,7 @@ def main():
     achieved_in_flight = bytes_per_launch * n_launches / elapsed / 1e9 if elapsed > 0 else 0.0
 
     # HBM traffic and the VALU mix of the dominant kernel: PMC counters cannot be read from inside this process; the
-    # per-launch figures come from profiles/r02/pmc_<workload>.json, which scripts/profile_r02.sh measured with rocprofv3
+    # per-launch figures come from profiles/r03/pmc_<workload>.json, which scripts/profile_r02.sh measured with rocprofv3
     # on serial launches (library defaults) -- used only if measured on the sources now in the tree, N = 1.
     traffic, valu, pmc_note = None, None, None
     if world == 1:
@@ -585,7 +680,7 @@ def main():
                             frac_in_flight=valu["weighted_issue_floor_ms"] / (1e3 * elapsed / args.steps))
 
     if rank == 0:
-        d = ctx.decode_acc(acc)
+        d = ctx.decode_acc(last_acc[0] if world == 1 else acc)
         fps = args.steps / elapsed
         out = {
             "metric": "frames/sec, 3840x2160 Dense-Grid sphere-trace (+ avg SDF-calls/pixel)" if args.workload == "C3"
@@ -598,7 +693,9 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        "row-tile shard x%d (%s, stripe %d, rank-0 share weighted) + RCCL gather of RGBA and per-rank "
                        "diagnostics sums to rank 0" % (world, args.partition, args.stripe)},
-            "setup_frames": setup_frames, "value_serial": value_serial,
+            "setup_frames": setup_frames, "value_serial": value_serial, "diagnostics": args.diagnostics,
+            "frames_verified": frames_verified, "frames_verified_how": verify_note,
+            "host_enqueue_ms": host_enqueue_ms if world > 1 else host_enqueue_ms[0],
             "avg_sdf_calls_per_pixel": d["total_sdf"] / (W * H), "avg_iterations_per_pixel": d["total_iters"] / (W * H),
             "max_sdf_calls": d["max_sdf"], "min_sdf_calls": d["min_sdf"],
             "sphere_evals_per_s": d["total_sdf"] * fps,

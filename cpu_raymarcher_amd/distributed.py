@@ -213,10 +213,13 @@ def gpu_render_rows(ctx, scene, width, height, shader, layout):
     return render_rows
 
 
-def gpu_render_all(ctx, scene, width, height, shader, layout, rank, extra=None):
+def gpu_render_all(ctx, scene, width, height, shader, layout, rank, extra=None, diag_in_tail=False):
     """render_all callback for the GPU and the interleaved partition: ONE rm_render_stripes_device
     launch writes every stripe of this rank into the packed buffer.  extra(packed) -> dict name -> device buffer for
-    outputs that are not sections of the layout (rank-local sdfEval / iters when only RGBA is gathered)."""
+    outputs that are not sections of the layout (rank-local sdfEval / iters when only RGBA is gathered).
+    diag_in_tail: the same launch leaves the diagnostics of this rank's rows (main.ts:528-548; sums, max and min
+    combine exactly over ranks) in the 32 bytes at layout.tail_offset, which travel with the gather
+    (rm_render_attach_diagnostics: no reduction launch)."""
     from . import _native as N
     from .host import _job
     if layout.mode != "interleaved":
@@ -230,12 +233,13 @@ def gpu_render_all(ctx, scene, width, height, shader, layout, rank, extra=None):
         def sec(name):
             return layout.section(packed, name) if name in want else local.get(name)
         job = _job(scene, width, height, 0.0, 0, height, "sphere-tracer")
+        diag = packed[layout.tail_offset:layout.tail_offset + 32] if diag_in_tail else None
         if layout.weights is not None:  # any deal of stripes: the launch takes the list
             ctx.render_stripe_list(job, layout.stripe, ids, sec("depth"), sec("normal"), sec("sdf"), sec("iters"),
-                                   rgba=sec("rgba"), shader=sh)
+                                   rgba=sec("rgba"), shader=sh, diag=diag)
         else:
             ctx.render_stripes(job, layout.stripe, layout.world, rank, sec("depth"), sec("normal"), sec("sdf"),
-                               sec("iters"), rgba=sec("rgba"), shader=sh)
+                               sec("iters"), rgba=sec("rgba"), shader=sh, diag=diag)
     ids = layout.stripe_ids(rank)
     return render_all
 

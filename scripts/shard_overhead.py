@@ -4,12 +4,19 @@ reassembly of the gathered frame + combined diagnostics (from stale receive buff
 S streams, for the equal stripe deal and for the weighted deal bench.py computes (distributed.balanced_weights from
 the same two measurements).  The N-GPU job's frame rate is bounded by its slowest rank: the table shows rank 0 is that
 rank under the equal deal and is not under the weighted one.
-usage: python scripts/shard_overhead.py [frames] [S=12] [N=8 ...] [WL=C3|C5]"""
+Round 3: the rank's diagnostics come from the render launch itself (FUSED=1, default; FUSED=0: round 2's two reduction
+launches), and GATHER=1 adds the call the real job makes per frame -- an asynchronous RCCL gather of the packed buffer on
+the frame's stream, through a ONE-rank process group (a one-GPU box cannot host two ranks: the transfer is a local copy,
+but the host-side cost of issuing it and of Work.wait() is the real one) -- to the host-enqueue column.
+usage: python scripts/shard_overhead.py [frames] [S=12] [N=8 ...] [WL=C3|C5] [FUSED=0|1] [GATHER=0|1]"""
 import os
 import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
@@ -22,8 +29,14 @@ def main():
     S = ([int(a[2:]) for a in sys.argv[1:] if a.startswith("S=")] or [12])[0]
     worlds = [int(a[2:]) for a in sys.argv[1:] if a.startswith("N=")] or [8]
     wl = ([a[3:] for a in sys.argv[1:] if a.startswith("WL=")] or ["C3"])[0]
+    fused = ([int(a[6:]) for a in sys.argv[1:] if a.startswith("FUSED=")] or [1])[0]
+    gather = ([int(a[7:]) for a in sys.argv[1:] if a.startswith("GATHER=")] or [0])[0]
     W, H = 3840, 2160
     dev = torch.device("cuda:0")
+    if gather:
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     ctx = R.Context(0)
     ctx.set_option("blocks_per_cu", 1)  # what bench.py uses with frames in flight
     ctx.set_option("lpt", 0)            # likewise: overlapping frames hide the tail the longest-first order is for
@@ -38,12 +51,15 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(S)]
     u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)  # noqa: E731
     i16 = lambda n: torch.zeros(n, dtype=torch.int16, device=dev)  # noqa: E731
-    print("workload %s, %dx%d, %d frames in flight, %d frames per measurement" % (wl, W, H, S, frames), flush=True)
+    print("workload %s, %dx%d, %d frames in flight, %d frames per measurement, diagnostics %s, %s"
+          % (wl, W, H, S, frames, "fused into the render launch" if fused else "two reduction launches",
+             "one-rank RCCL gather issued per frame" if gather else "no gather call"), flush=True)
 
     def rank_frame_ms(layout, rank, with_asm):
         cur = [None]
-        ra = D.gpu_render_all(ctx, scene, W, H, "iteration-heatmap", layout, rank, extra=lambda packed: cur[0])
-        sets = [dict(p=u8(layout.nbytes), sdf=i16(layout.cap * W), iters=i16(layout.cap * W)) for _ in range(S)]
+        ra = D.gpu_render_all(ctx, scene, W, H, "iteration-heatmap", layout, rank, extra=lambda packed: cur[0], diag_in_tail=bool(fused))
+        sets = [dict(p=u8(layout.nbytes), sdf=i16(layout.cap * W), iters=i16(layout.cap * W), recv=[u8(layout.nbytes)] if gather else None,
+                     work=None) for _ in range(S)]
         px = W * sum(b - a for a, b in layout.rows(rank))
         asm = D.GpuFrameAssembler(layout, dev, S, ctx=ctx) if with_asm else None
         acc = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -56,9 +72,17 @@ def main():
                 b = sets[k]
                 with torch.cuda.stream(streams[k]):
                     cur[0] = b
+                    if b["work"] is not None:
+                        b["work"].wait()  # the buffer's previous gather has been consumed (ShardedFrameRenderer._submit)
                     ra(b["p"])
-                    ctx.reduce_counters_enqueue(b["sdf"][:px], b["iters"][:px],
-                                                b["p"][layout.tail_offset:layout.tail_offset + 32].view(torch.int64))
+                    if not fused:
+                        ctx.reduce_counters_enqueue(b["sdf"][:px], b["iters"][:px],
+                                                    b["p"][layout.tail_offset:layout.tail_offset + 32].view(torch.int64))
+                    if gather:
+                        b["work"] = dist.gather(b["p"], b["recv"], dst=0, async_op=True)
+                        if asm:
+                            b["work"].wait()
+                            b["work"] = None
                     if asm:
                         asm.assemble(k, acc)
             t_host = time.perf_counter() - t0
@@ -82,6 +106,11 @@ def main():
         print("N=%d  weighted deal: rank 0 (render %4d rows + reassembly + diagnostics) %.3f ms/frame | rank 1 (render %4d rows) %.3f ms/frame"
               "  -> job <= %.0f frames/s   weights %s [host enqueue %.3f / %.3f ms]"
               % (world, rows(bal, 0), b_root, rows(bal, 1 % world), b_other, 1e3 / max(b_root, b_other), weights[:2], hb_root, hb_other), flush=True)
+
+
+    if gather:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -82,12 +82,12 @@ struct rm_ctx {
     int64_t opt_grid = 1;
     int64_t opt_nn = 2;  // per-cell nearest-candidate lists for the all-primitive fallback: 0 off, 1 on, 2 auto (scenes of
                          // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
-    int64_t opt_blocks_per_cu = 4;  // persistent workgroups per launch and CU (a frame alone: 4 beats 5, 2.02 against 2.07 ms)
+    int64_t opt_blocks_per_cu = 6;  // persistent workgroups per launch and CU: what the kernel's 80 VGPRs and 26 KB of LDS allow (a frame alone, round 3: 4: 1.42 ms, 6: 1.32, 7: 1.30)
+    int64_t opt_lds_fill = 0;
     int64_t opt_lds_kb = 0;         // v2: LDS budget per workgroup the launcher trims the hit lists to (0: as many workgroups per CU as the kernel's registers allow; 32: five per CU, 40: four)
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
-    int64_t opt_static = 0;  // v2: percent of every tile queue assigned to the waves without atomics.  Worth +7 % when
-                             // frames overlap (bench.py sets 75 with frames in flight); alone it costs the frame its balance
+    int64_t opt_static = 0;  // accepted and ignored since round 3 (a static share of every tile queue, overtaken in round 2; the 64 queue heads of round 3 removed its reason)
     int64_t opt_lut = 1;   // Octree.findNode through the 64^3 cell table
     int64_t opt_cull = 1;     // v2: whole 64-pixel batches find their hit leaves by a bundle-frustum cull instead of the tree walk
     int64_t opt_rel = 1;      // v2: BVH node boxes relative to the frame's ray origin, as doubles in LDS (slab test without conversions)
@@ -101,9 +101,10 @@ struct rm_ctx {
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
     // permutation and records its own costs); geometry changes restart the feedback
     static constexpr int kLptSlots = 16;
-    static constexpr int kLptStride = 16384;  // items per XCD queue (8 queues); larger frames render without LPT
-    uint8_t *d_lpt_cost = nullptr;    // [kLptSlots][8 * kLptStride]
-    uint16_t *d_lpt_perm = nullptr;   // [kLptSlots][8 * kLptStride]
+    static constexpr int kLptQueues = 64;     // rm_render_v2.hip RM_QUEUES
+    static constexpr int kLptStride = 4096;   // items per queue; larger frames render without LPT
+    uint8_t *d_lpt_cost = nullptr;    // [kLptSlots][kLptQueues * kLptStride]
+    uint16_t *d_lpt_perm = nullptr;   // [kLptSlots][kLptQueues * kLptStride]
     unsigned int lpt_launch = 0;
     long long lpt_geometry = -1;
     hipEvent_t lpt_done[16] = {};  // recorded after the launch that owns the slot: a slot is reused only once that launch is over
@@ -136,7 +137,7 @@ struct rm_ctx {
     };
     std::vector<DevTable> tables;
     int64_t opt_item_px = 128;  // two 64-pixel batches per queue claim: 7-10 % faster than 64 at the end of round 1, 256 loses
-    unsigned int *d_counters = nullptr;  // ring of 1024 x 8 queue heads: a launch owns its slot until 1023 later launches
+    unsigned int *d_counters = nullptr;  // ring of 1024 x 64 queue heads, 256 bytes apart (rm_render_v2.hip RM_QSTRIDE): a launch owns its slot until 1023 later launches
                                          // have been enqueued (frames in flight on several streams each need their own)
     unsigned int counter_slot = 0;
     // Fused diagnostics (rm_diag.h): a ring of accumulator blocks, one per launch in flight like the queue heads above;
@@ -218,7 +219,7 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
         p.oct_frame = oct_slot ? oct_slot->dev : nullptr;  // null: the launcher takes render_kernel<1, false, 0>
     }
     if (ctx->opt_lpt && p.variant == 2 && p.algorithm == 0) {  // longest-first item order (rm_render_v2.hip, lpt_sort_kernel)
-        const size_t per_slot = static_cast<size_t>(8) * rm_ctx::kLptStride;
+        const size_t per_slot = static_cast<size_t>(rm_ctx::kLptQueues) * rm_ctx::kLptStride;
         if (!ctx->d_lpt_cost) {
             if (hipMalloc(reinterpret_cast<void **>(&ctx->d_lpt_cost), rm_ctx::kLptSlots * per_slot) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void **>(&ctx->d_lpt_perm), rm_ctx::kLptSlots * per_slot * sizeof(uint16_t)) != hipSuccess) {
@@ -570,8 +571,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.refill_threshold = static_cast<int32_t>(ctx->opt_refill);
     p.hw_xcd = static_cast<int32_t>(ctx->opt_hw_xcd);
     p.item_px = static_cast<int32_t>(ctx->opt_item_px);
-    p.static_share = static_cast<int32_t>(ctx->opt_static);
-    p.tile_counters = ctx->d_counters ? ctx->d_counters + 8 * (ctx->counter_slot++ % 1024) : nullptr;
+    p.tile_counters = ctx->d_counters ? ctx->d_counters + 64 * 64 * (ctx->counter_slot++ % 1024) : nullptr;
     p.stamps = ctx->d_stamps;
     for (int k = 0; k < 3; ++k) {
         p.pq_dim[k] = ctx->host.pq_dim[k];
@@ -601,6 +601,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.prim_filter = (ctx->opt_filter && ctx->host.general && !ctx->host.program && ctx->host.prim_filter_ok &&
                      ctx->host.spheres.size() == ctx->host.prims.size()) ? 1 : 0;
     p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
+    p.lds_fill = static_cast<int32_t>(ctx->opt_lds_fill);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2 &&
         ctx->host.spheres.size() <= 256) {  // one radius, bit for bit; at most 256 spheres: the scan keys carry the id in eight bits
@@ -652,8 +653,8 @@ int rm_create(int device, rm_ctx **out) {
         e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag), sizeof(RmDiagDevice));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 8 * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 1024 * 8 * sizeof(unsigned int));  // every launch leaves its heads zeroed (rm_diag.h)
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_counters), 1024 * 64 * 64 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, 1024 * 64 * 64 * sizeof(unsigned int));  // every launch leaves its heads zeroed (rm_diag.h)
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_diag_blocks), rm_ctx::kDiagBlocks * sizeof(RmDiagBlock));
         if (e == hipSuccess) e = hipMemset(ctx->d_diag_blocks, 0, rm_ctx::kDiagBlocks * sizeof(RmDiagBlock));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), (40 + 3 * 8192 + 2048 * 48) * sizeof(unsigned long long));
@@ -1318,6 +1319,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lds_kb = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "lds_fill")) {
+        ctx->opt_lds_fill = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "cull")) {
         ctx->opt_cull = value ? 1 : 0;
         return RM_OK;
@@ -1416,6 +1421,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "rel")) *value = ctx->opt_rel;
     else if (!std::strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
+    else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

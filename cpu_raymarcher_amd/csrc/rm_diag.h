@@ -72,7 +72,7 @@ __device__ __forceinline__ void diag_finalise_body(RmDiagBlock *blk, RmDiagDevic
         out->pad = 0;
     }
     if (lane == 0) __hip_atomic_store(&blk->slots_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tile_counters && lane < 8) __hip_atomic_store(&tile_counters[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile_counters) __hip_atomic_store(&tile_counters[lane * 64u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the v2 kernels' 64 queue heads, 256 bytes apart (RM_QSTRIDE)
 }
 
 __device__ __attribute__((noinline)) static void diag_finalise(RmDiagBlock *blk, RmDiagDevice *out, unsigned int *tile_counters,

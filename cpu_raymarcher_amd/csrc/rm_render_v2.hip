@@ -779,46 +779,81 @@ __device__ __forceinline__ const T *stage(unsigned char *smem, size_t &off, cons
     return dst;
 }
 
-// Wave-granular work queue: a work item is one tile of item_px (64, 128 or 256) pixels, tile_w
-// wide and item_px / tile_w tall.
-// XCD x owns the tile rows r with r % 8 == x, so the partial-line stores of horizontally
-// adjacent tiles meet in one L2; a wave whose XCD queue is empty steals from the others.
+// Wave-granular work queues: a work item is one tile of item_px (64, 128 or 256) pixels, tile_w wide and item_px / tile_w
+// tall.  XCD x owns the tile rows r with r % 8 == x, so the partial-line stores of horizontally adjacent tiles meet in
+// one L2.  Round 3: every XCD's rows are dealt over RM_SUBQ sub-queues (row x + 8 m belongs to sub-queue m % RM_SUBQ), 64
+// queue heads instead of 8.  A queue head is ONE address that every claim of that queue must pass through, and a
+// device-scope read-modify-write on one address completes every ~146 ns (measured: a 4K frame of 64-pixel items took
+// 16 200 claims x 146 ns = 2.37 ms however many waves were resident): with eight heads a frame alone could not use items
+// smaller than 128 pixels, and its slowest items (a 256-pixel item whose four batches each hold a 100-step grazing ray:
+// 400 wave-loop trips in series) set its duration.  A wave serves one home queue (its XCD, sub-queue by workgroup) and,
+// when that is empty, looks at all 64 heads at once (one per lane) and takes from the nearest queue that has entries left.
+// The heads sit RM_QSTRIDE words (256 bytes) apart: device-scope atomics on one 128-byte line are performed one after the
+// other whichever word they name (microbenchmark, 6144 waves x 32 claims: 64 heads 4 bytes apart 4.7 ns per claim over
+// the whole chip, 256 bytes apart 0.25 ns), and with thousands of waves in the queue for that line a claim took 13 us.
+#define RM_SUBQ 8
+#define RM_QUEUES (8 * RM_SUBQ)
+#define RM_QSTRIDE 64
+inline int queue_rows_host(int tiles_y, int qid) {
+    const int x = qid / RM_SUBQ, s = qid % RM_SUBQ, Rx = (tiles_y - x + 7) >> 3;
+    return Rx > s ? (Rx - s + RM_SUBQ - 1) / RM_SUBQ : 0;
+}
 struct TileQueue {
-    unsigned int *counters;  // one per XCD, zeroed by the host before the launch
+    unsigned int *counters;  // RM_QUEUES heads, zero before the launch (the previous user's last wave leaves them so)
     int tiles_x, tiles_y, tile_w, tile_h, item_px;
     unsigned int tiles_x_magic;  // floor(2^32 / tiles_x) + 1; 0 for tiles_x == 1
-    unsigned int base;           // first queue entry handed out dynamically (the ones before it are assigned statically)
-    const uint16_t *perm;        // longest-first order of every queue (null: the queue's own order), lpt_stride entries apart
+    const uint16_t *perm;        // longest-first order of every queue (null: the queue's own order), perm_stride entries apart
     int perm_stride;
 };
 
-// next tile for this wave; false when every queue is exhausted.  `home` rotates on a steal.
-// entry q of XCD queue x -> tile (row, col); false beyond the queue's end.  XCD x owns the R tile rows x, x + 8, ...;
-// they are handed out from the middle of the frame outwards, so the light rows near the top and bottom edges (rays that
-// miss everything) come last and pack the frame's tail.
-__device__ __forceinline__ bool queue_entry(const TileQueue &Q, int x, unsigned int k, int &tile_col, int &tile_row) {
-    const int R = (Q.tiles_y - x + 7) >> 3;
-    if (Q.perm) {  // the k-th item to hand out is the one the previous frame found k-th longest (any permutation is valid)
-        if (k >= static_cast<unsigned int>(R) * static_cast<unsigned int>(Q.tiles_x)) return false;
-        k = Q.perm[static_cast<size_t>(x) * Q.perm_stride + k];
-    }
+// tile rows of queue qid = x * RM_SUBQ + s: the rows x + 8 m with m % RM_SUBQ == s
+__device__ __forceinline__ int queue_rows(int tiles_y, int qid) {
+    const int x = qid / RM_SUBQ, s = qid % RM_SUBQ;
+    const int Rx = (tiles_y - x + 7) >> 3;  // rows of XCD x (may be <= 0)
+    return Rx > s ? (Rx - s + RM_SUBQ - 1) / RM_SUBQ : 0;
+}
+
+// entry k of queue qid -> tile (row, col); false beyond the queue's end.  A queue's rows are handed out from the middle
+// of the frame outwards, so the light rows near the top and bottom edges (rays that miss everything) come last.
+__device__ __forceinline__ bool queue_entry(const TileQueue &Q, int qid, unsigned int k, int &tile_col, int &tile_row) {
+    const int R = queue_rows(Q.tiles_y, qid);
+    if (k >= static_cast<unsigned int>(R) * static_cast<unsigned int>(Q.tiles_x)) return false;
+    if (Q.perm) k = Q.perm[static_cast<size_t>(qid) * Q.perm_stride + k];  // the k-th item to hand out is the one the previous frame found k-th longest
     const unsigned int q = Q.tiles_x_magic ? __umulhi(k, Q.tiles_x_magic) : k;  // k / tiles_x (exact: k * tiles_x < 2^32)
     const int qi = static_cast<int>(q), mid = R >> 1;
     const int j = (qi & 1) ? mid - ((qi + 1) >> 1) : mid + (qi >> 1);
-    tile_row = j * 8 + x;
+    tile_row = (qid / RM_SUBQ) + 8 * ((qid % RM_SUBQ) + RM_SUBQ * j);
     tile_col = static_cast<int>(k - q * static_cast<unsigned int>(Q.tiles_x));
-    return qi < R;
+    return true;
+}
+// ... and back: the slot (row slot * tiles_x + col) of a tile in its queue (for the cost feedback of the longest-first order)
+__device__ __forceinline__ unsigned int queue_slot_of(const TileQueue &Q, int qid, int tile_col, int tile_row) {
+    const int R = queue_rows(Q.tiles_y, qid), mid = R >> 1;
+    const int j = (tile_row >> 3) / RM_SUBQ;
+    const int qi = j >= mid ? 2 * (j - mid) : 2 * (mid - j) - 1;
+    return static_cast<unsigned int>(qi) * static_cast<unsigned int>(Q.tiles_x) + static_cast<unsigned int>(tile_col);
 }
 
-// `first_claim`: lane 0's result of an atomicAdd on the home queue that the caller issued earlier (so that its round
-// trip overlaps the pixel stores); the first attempt consumes it instead of issuing its own.
+// next tile for this wave; false when every queue is exhausted.  `first_claim`: lane 0's result of an atomicAdd on the
+// home queue that the caller issued earlier (so that its round trip overlaps the pixel stores).  When the home queue is
+// empty, lane l reads head l (device scope) and the wave takes from the first queue after `home` -- the rest of its own
+// XCD's sub-queues come first -- that still has entries; a claim that loses the race for a queue's last entry looks again.
+// Heads only grow, so every look either succeeds or finds one more queue exhausted: the loop ends.
 __device__ __forceinline__ bool pull_tile(const TileQueue &Q, int &home, int &tile_col, int &tile_row, int lane,
                                           unsigned int first_claim) {
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        const int x = (home + attempt) & 7;
-        unsigned int k = first_claim;
-        if (attempt > 0 && lane == 0) k = atomicAdd(&Q.counters[x], 1u);
-        k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k))) + Q.base;
+    unsigned int k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(first_claim)));
+    if (queue_entry(Q, home, k, tile_col, tile_row)) return true;
+    const unsigned int mine = static_cast<unsigned int>(queue_rows(Q.tiles_y, lane)) * static_cast<unsigned int>(Q.tiles_x);  // RM_QUEUES == 64 lanes
+    for (int attempt = 0; attempt < 4096; ++attempt) {  // (the bound is never reached: see above)
+        const unsigned int head = __hip_atomic_load(&Q.counters[lane * RM_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long avail = __ballot(head < mine);
+        if (avail == 0) return false;
+        const int h = (home + 1) & (RM_QUEUES - 1);
+        const unsigned long long rot = h ? ((avail >> h) | (avail << (RM_QUEUES - h))) : avail;
+        const int x = (h + __builtin_ctzll(rot)) & (RM_QUEUES - 1);
+        k = 0;
+        if (lane == 0) k = atomicAdd(&Q.counters[x * RM_QSTRIDE], 1u);
+        k = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
         if (queue_entry(Q, x, k, tile_col, tile_row)) {
             home = x;
             return true;
@@ -852,7 +887,8 @@ template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ WaveDiag wave_diag[4];
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;  // (used before the wave loop only: inside it the lane id is re-derived where needed, see lane_now)
+    const int lane = lane0;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // wave-uniform by construction: an SGPR, not a VGPR held for the whole kernel
     if (lane < 8) {  // (LDS operations of one wave execute in order: no barrier between this and the wave's own atomics)
         wave_diag[wave].sdf[lane] = 0;
@@ -901,21 +937,29 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
         }
     }
     const int list_cap = P.list_cap;
+    // The lane id inside the wave loop: two v_mbcnt where it is used (opaque to the optimiser: a value derived from
+    // threadIdx would be kept in a register for the whole kernel, and the kernel has exactly as many as six waves allow).
+    auto lane_now = []() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     // this lane's column of the wave's hit-leaf lists (entry e at [e * 64]).  Formed where it is used, from parameters loaded
     // there: a loop-invariant address would be hoisted into a register that lives for the whole kernel.
     auto list_column = [&](const RmRenderParams &C) {
         const uint32_t end = C.lds_off[9];
-        return reinterpret_cast<uint16_t *>(smem + end) + (static_cast<uint32_t>(wave) * static_cast<uint32_t>(C.list_cap)) * 64u + static_cast<uint32_t>(lane);
+        return reinterpret_cast<uint16_t *>(smem + end) + (static_cast<uint32_t>(wave) * static_cast<uint32_t>(C.list_cap)) * 64u + static_cast<uint32_t>(lane_now());
     };
     const int item_px = P.item_px;
-    // HW_REG_XCC_ID (id 20, bits [3:0]): the XCD this wave really runs on; blockIdx % 8 otherwise
-    int home = P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7);
+    // home queue: the XCD this wave really runs on (HW_REG_XCC_ID, id 20, bits [3:0]; blockIdx % 8 otherwise), and the
+    // sub-queue its workgroup's number within the XCD selects (workgroups go to the XCDs round-robin)
+    int home = (P.hw_xcd ? (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7) : (static_cast<int>(blockIdx.x) & 7)) * RM_SUBQ +
+               static_cast<int>((blockIdx.x >> 3) % RM_SUBQ);
     const int refill_at = P.refill_threshold;  // refill as soon as this many lanes are idle
 
     // ---- wave state: the tile being consumed ------------------------------------------------
     int tile_col = -1, tile_row = 0, qpos = item_px;  // tile_col < 0: no item yet; qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
-    int static_j = 0;
     unsigned int item_iters = 0;  // cost feedback for the next frame's longest-first order: wave-loop iterations spent on the current item
 
     // ---- lane state (round 3: 21 registers instead of ~44; registers decide this kernel's occupancy) ----------------
@@ -988,7 +1032,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
         const bool miss = t >= RM_MAX_DIST;
         const float nx = miss ? 0.f : nrm_x(), ny = miss ? 0.f : nrm_y(), nz = miss ? 0.f : __int_as_float(sC);
         store_pixel(C, static_cast<size_t>(pidx), t, nx, ny, nz, counters >> 16, counters & 0xFFFFu);
-        if (C.diag_out) wave_diag_add(&wave_diag[wave], lane, counters >> 16, counters & 0xFFFFu);
+        if (C.diag_out) wave_diag_add(&wave_diag[wave], lane_now(), counters >> 16, counters & 0xFFFFu);
     };
 
     RM_T0()
@@ -1024,53 +1068,38 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
             Q.tiles_x = C.tiles_x;
             Q.tiles_y = C.tiles_y;
             Q.tiles_x_magic = C.tiles_x_magic;
-            Q.base = static_cast<unsigned int>(C.queue_base);
             Q.perm = C.lpt_perm;
             Q.perm_stride = C.lpt_stride;
-            // The queue atomic is issued BEFORE the pixel stores and its result consumed after them: the wait for the
-            // returned value (s_waitcnt vmcnt counts in order) then no longer covers the completion of the seven stores,
-            // which was 23 % of the wave cycles in the stamps build.
             const bool want_tile = !no_more && qpos >= Q.item_px;
-            const bool want_static = want_tile && static_j < C.static_per_wave;
-            unsigned int claim = 0;
-#ifdef RM_STAMPS_CLAIM  // diagnostic: the queue atomic's round trip, waited for at once (the product overlaps it with the stores)
-            if (want_tile && !want_static) {
-                const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
-                if (lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned long long tc1 = __builtin_amdgcn_s_memrealtime();
-                if (lane == 0 && P.stamps) {
-                    atomicAdd(&P.stamps[38], tc1 - tc0);
-                    atomicAdd(&P.stamps[39], 1ull);
+            const int lane_r = lane_now();
+            if (want_tile) {
+                // (before the pixel stores are issued: the wait for the claim's answer then covers no store of this refill.
+                // Tried in round 3 and dropped: claiming one item AHEAD so that the answer is never waited for -- no gain with
+                // frames in flight (919 against 949 frames/s), none alone, one more register held across the wave loop.)
+                if (C.lpt_cost_out && tile_col >= 0) {  // the item just finished: what it cost, at its slot of the queue it was pulled from (= home)
+                    if (lane_r == 0) C.lpt_cost_out[static_cast<size_t>(home) * C.lpt_stride + queue_slot_of(Q, home, tile_col, tile_row)] =
+                        static_cast<uint8_t>(item_iters < 255u ? item_iters : 255u);
                 }
-            }
-#else
-            if (want_tile && !want_static && lane == 0) claim = atomicAdd(&Q.counters[home], 1u);
+#ifdef RM_STAMPS_CLAIM  // diagnostic: how long does the wave wait for its claim?
+                const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
 #endif
-            if ((st & (ST_PHASE | ST_PIXEL)) == (PH_DONE | ST_PIXEL)) {
-                store_mine(C);
-                st &= ~ST_PIXEL;
-            }
-            if (want_tile && C.lpt_cost_out && tile_col >= 0) {  // the item just finished: what it cost.  Its place in its queue
-                // follows from its tile: the queue is the one it was pulled from (= home), the row slot inverts queue_entry
-                const int R = (Q.tiles_y - home + 7) >> 3, j = tile_row >> 3, mid = R >> 1;
-                const int qi = j >= mid ? 2 * (j - mid) : 2 * (mid - j) - 1;
-                if (lane == 0) C.lpt_cost_out[static_cast<size_t>(home) * C.lpt_stride + static_cast<size_t>(qi) * Q.tiles_x + tile_col] =
-                    static_cast<uint8_t>(item_iters < 255u ? item_iters : 255u);
-            }
-            if (want_static) {  // no atomic: workgroup b serves queue b % 8 (the XCD it is dispatched to under round-robin
-                                // placement; coverage does not depend on that), its wave w the entries rank + waves/8 * j
-                const int x = static_cast<int>(blockIdx.x) & 7;
-                const unsigned int k = static_cast<unsigned int>(((static_cast<int>(blockIdx.x) >> 3) << 2) + wave +
-                                                                 (C.total_waves >> 3) * static_j);
-                static_j += 1;
-                queue_entry(Q, x, k, tile_col, tile_row);
-                qpos = 0;
-            } else if (want_tile) {
-                if (pull_tile(Q, home, tile_col, tile_row, lane, claim)) {
+                unsigned int claim = 0;
+                if (lane_r == 0) claim = atomicAdd(&Q.counters[home * RM_QSTRIDE], 1u);
+                if (pull_tile(Q, home, tile_col, tile_row, lane_r, claim)) {
                     qpos = 0;
                     item_iters = 0;
                 } else no_more = true;
+#ifdef RM_STAMPS_CLAIM
+                const unsigned long long tc1 = __builtin_amdgcn_s_memrealtime();
+                if (lane_r == 0 && P.stamps) {
+                    atomicAdd(&P.stamps[38], tc1 - tc0);
+                    atomicAdd(&P.stamps[39], 1ull);
+                }
+#endif
+            }
+            if ((st & (ST_PHASE | ST_PIXEL)) == (PH_DONE | ST_PIXEL)) {
+                store_mine(C);
+                st &= ~ST_PIXEL;
             }
             if (!no_more) {
                 const int remaining = Q.item_px - qpos;
@@ -1120,7 +1149,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                         const int r0 = (tile_row << C.tile_h_log2) + batch_sub * (64 >> C.tile_w_log2);
                         const Bundle B = make_bundle(C, x0, x0 + Q.tile_w - 1, row_to_y(C, r0),
                                                      row_to_y(C, r0 + (64 >> C.tile_w_log2) - 1));
-                        hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane);
+                        hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane_now());
                     } else if (in_frame) {
                         RM_CNT(15)
                         hc = bvh_prologue<REL>(scene_view<ACCEL, LDS, REL>(C, smem), ray, ri, L, cur);
@@ -1252,6 +1281,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
         const bool coop = CB.coop != 0, filter = CB.filter != 0;
         const bool use_grid = ACCEL == 2 && CB.use_grid != 0;
         double dist;
+        const int lane_b = lane_now();
         uint32_t evaluated = 0;  // primitives this round counts (raymarcher.ts:117-119)
         NormalAux aux;
         aux.ok = false;
@@ -1261,18 +1291,18 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
         if (ACCEL == 2) {
 #ifdef RM_STAMPS
             unsigned long long fbc = 0;
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, &fbc, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, &fbc);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, &fbc, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, &fbc);
             t_acc_[4] += fbc;
             t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
 #else
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, nullptr, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane, coop, filter, use_grid, nullptr);
+            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, nullptr, &aux);
+            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, nullptr);
 #endif
         }
         else if (ACCEL == 1) dist = need ? oct_distance_lane(SB, onode, q, evaluated, filter) : RM_MAX_DIST;
         else {
-            dist = all_prims_wave(SB, need, q, lane, coop, filter);
+            dist = all_prims_wave(SB, need, q, lane_b, coop, filter);
             if (need) evaluated = static_cast<uint32_t>(SB.n_prims);
         }
         counters += evaluated << 16;  // Uint16Array += : the carry out of the upper half is the wrap
@@ -1348,7 +1378,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                 mi = w->mn_inv[k] > mi ? w->mn_inv[k] : mi;
             }
             diag_flush_wave(C.diag_block, C.diag_out, C.tile_counters, ts, ti, mx, mi, blockIdx.x * 4u + static_cast<unsigned int>(wave),
-                            gridDim.x * 4u, lane);
+                            gridDim.x * 4u, lane_now());
         }
     }
 #ifdef RM_COUNTS
@@ -1378,14 +1408,14 @@ namespace {
 // nearly the same picture again, and any permutation is a valid order, so stale or missing costs only cost balance).
 // A frame that runs alone ends with a ramp: its 4096 waves finish over the last ~0.5 ms (scripts/tail_hist.py), because a
 // wave's last item may be one with a 100-step grazing ray.  Handing out the expensive items first leaves cheap ones for the
-// end.  One workgroup per XCD queue; four cost classes (>= 4, 2, 1.25 x the mean, the rest) and a STABLE partition, so that
+// end.  One workgroup per queue (RM_QUEUES); four cost classes (>= 4, 2, 1.25 x the mean, the rest) and a STABLE partition, so that
 // inside a class the queue keeps its own order -- horizontally adjacent tiles stay adjacent in time and their partial-line
 // stores still merge in L2.  The costs are copied to LDS first: the previous launch may still be writing them, and the
 // permutation must be built from ONE snapshot to be a permutation.
 __global__ __launch_bounds__(1024) void lpt_sort_kernel(const uint8_t *cost_prev, uint16_t *perm, int stride, int tiles_x, int tiles_y) {
     extern __shared__ unsigned char lpt_smem[];
-    const int x = blockIdx.x;
-    const int R = (tiles_y - x + 7) >> 3;
+    const int x = blockIdx.x;  // queue id
+    const int R = queue_rows(tiles_y, x);
     const int n = R * tiles_x;
     uint8_t *cost = lpt_smem;                                                   // n bytes
     unsigned int *cnt = reinterpret_cast<unsigned int *>(lpt_smem + ((stride + 15) & ~15));  // [4][1024]
@@ -1432,7 +1462,7 @@ __global__ __launch_bounds__(1024) void lpt_sort_kernel(const uint8_t *cost_prev
 }  // namespace
 hipError_t rm_launch_lpt_sort(const uint8_t *cost_prev, uint16_t *perm, int stride, int tiles_x, int tiles_y, hipStream_t stream) {
     const size_t shmem = static_cast<size_t>((stride + 15) & ~15) + 4 * 1024 * sizeof(unsigned int);
-    hipLaunchKernelGGL(lpt_sort_kernel, dim3(8), dim3(1024), shmem, stream, cost_prev, perm, stride, tiles_x, tiles_y);
+    hipLaunchKernelGGL(lpt_sort_kernel, dim3(RM_QUEUES), dim3(1024), shmem, stream, cost_prev, perm, stride, tiles_x, tiles_y);
     return hipGetLastError();
 }
 #endif
@@ -1503,7 +1533,14 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
             rel = false;
         }
     }
-    const size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
+    size_t shmem = (lds ? scene_bytes : 0) + (rel ? rel_bytes + 16 : 0) + list_bytes + 16;
+    // Option `lds_fill`: a launch of k persistent workgroups per CU asks for as much LDS as still lets k of them share a CU, so
+    // that the dispatcher CANNOT put more than k on one CU (and fewer on another): a frame that runs alone gets exactly k on
+    // every CU.  Never with one workgroup per CU (frames in flight: the CU is to be shared with the other launches).
+    if (p.lds_fill && p.blocks_per_cu >= 2 && p.blocks_per_cu <= 8) {
+        const size_t room = (160 * 1024 / static_cast<size_t>(p.blocks_per_cu)) / 1280 * 1280 - sizeof(WaveDiag) * 4;
+        if (room > shmem && room <= 64 * 1024) shmem = room;
+    }
     {
         const LdsLayout lay = lds_layout_host(p, p.accel, lds, rel && p.accel == 2);
         const uint32_t v[10] = {lay.nodes, lay.prims, lay.cells, lay.list, lay.oct, lay.oct_prims, lay.spheres, lay.radii, lay.rel, lay.end};
@@ -1512,26 +1549,15 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
     }
     resident = static_cast<unsigned>(p.num_cus > 0 ? p.num_cus : 256) * static_cast<unsigned>(p.blocks_per_cu > 0 ? p.blocks_per_cu : 4);
     blocks = needed < resident ? (needed ? needed : 1u) : resident;
-    // static share: three quarters of the shortest queue, in whole rounds over all waves
-    p.total_waves = static_cast<int32_t>(blocks * 4);
-    p.static_per_wave = 0;
-    p.queue_base = 0;
-    if (p.static_share > 0 && blocks % 8 == 0) {
-        const long long min_rows = tiles_y / 8;  // every queue owns at least this many tile rows
-        const long long per_round = p.total_waves / 8;  // queue entries one round of all waves consumes per queue
-        const long long rounds = (min_rows * tiles_x * p.static_share / 100) / per_round;
-        p.static_per_wave = static_cast<int32_t>(rounds);
-        p.queue_base = static_cast<int32_t>(rounds * per_round);
-    }
     // the tile-queue heads are zero: a launch's last wave leaves them so (rm_diag.h).  Without an accumulator block
     // (a caller below the API layer) they are cleared here.
     hipError_t e = hipSuccess;
-    if (!p.diag_block) e = hipMemsetAsync(p.tile_counters, 0, 8 * sizeof(unsigned int), stream);
+    if (!p.diag_block) e = hipMemsetAsync(p.tile_counters, 0, RM_QUEUES * RM_QSTRIDE * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     // longest-first item order (option `lpt`): the api layer hands in the cost / permutation buffers and their stride
     p.lpt_perm = nullptr;
-    if (p.lpt_perm_out && p.static_per_wave == 0) {
-        const long long per_queue = static_cast<long long>((tiles_y + 7) / 8) * tiles_x;
+    if (p.lpt_perm_out) {
+        const long long per_queue = static_cast<long long>(queue_rows_host(tiles_y, 0)) * tiles_x;  // queue 0 is never shorter than another
         if (per_queue <= p.lpt_stride && per_queue <= 32768) {
             e = rm_launch_lpt_sort(p.lpt_cost_prev, p.lpt_perm_out, p.lpt_stride, tiles_x, tiles_y, stream);
             if (e != hipSuccess) return e;

@@ -157,7 +157,7 @@ struct RmRenderParams {
     int32_t n0_batch;          // v2 BVH: lanes waiting for getNormal that trigger the normal round while others still march (64: never)
     const int32_t *stripe_ids; // non-null (with stripe_rows > 0): the launch renders the stripes stripe_ids[0 .. ) in this
                                // order (increasing), packed; any deal of stripes to parts, e.g. a weighted one
-    unsigned int *tile_counters;  // v2: 8 work-queue heads (one per XCD), zeroed per launch
+    unsigned int *tile_counters;  // v2: 64 work-queue heads (8 XCDs x 8 sub-queues), zero before and after a launch
     unsigned long long *stamps;   // diagnostic build (-DRM_STAMPS) only: 8 cycle accumulators
     const uint32_t *pq_cells;
     const uint16_t *pq_list;
@@ -172,11 +172,7 @@ struct RmRenderParams {
     // are powers of two; k / tiles_x through a magic multiplier, exact for k * tiles_x < 2^32)
     int32_t tile_w_log2, tile_h_log2, tiles_x, tiles_y;
     uint32_t tiles_x_magic;
-    // v2: the first `static_per_wave` items of every wave are assigned without an atomic (wave g takes entries
-    // g + total_waves * j of the interleaved queues); the queues hand out the rest, starting at queue_base
-    int32_t static_per_wave, queue_base, total_waves;
     int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = six workgroups per CU, then five, then four)
-    int32_t static_share;  // percent of the shortest queue assigned statically (option; 0 = all dynamic)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads
     int32_t nn_dim[3];   // the nearest-candidate grid has its own (finer) resolution over the root box
     float nn_inv[3];
@@ -209,6 +205,7 @@ struct RmRenderParams {
     // Fused diagnostics (rm_diag.h; main.ts:528-548): the launch's accumulator block (from a ring in rm_api.cpp; all zero
     // before and after the launch) and where the launch's last wave writes the 32-byte result (null: no diagnostics).
     // v2 launches always carry a block: the last wave also re-zeroes the launch's tile-queue heads.
+    int32_t lds_fill, lds_fill_pad;  // v2: option `lds_fill` (rm_render_v2.hip: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU)
     RmDiagBlock *diag_block;
     RmDiagDevice *diag_out;
 };

@@ -84,6 +84,7 @@ struct rm_ctx {
                          // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
     int64_t opt_blocks_per_cu = 6;  // persistent workgroups per launch and CU: what the kernel's 80 VGPRs and 26 KB of LDS allow (a frame alone, round 3: 4: 1.42 ms, 6: 1.32, 7: 1.30)
     int64_t opt_lds_fill = 0;
+    int64_t opt_multi_step = 1;  // v2 BVH: in-round march steps (rm_render_v2.hip, section M)
     int64_t opt_lds_kb = 0;         // v2: LDS budget per workgroup the launcher trims the hit lists to (0: as many workgroups per CU as the kernel's registers allow; 32: five per CU, 40: four)
     int64_t opt_refill = 64;
     int64_t opt_recs = 1;  // octree leaves read leaf-ordered sphere records
@@ -577,6 +578,8 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
         p.pq_dim[k] = ctx->host.pq_dim[k];
         p.pq_origin[k] = ctx->host.pq_origin[k];
         p.pq_inv[k] = ctx->host.pq_inv[k];
+        // cell size, rounded down a little: it scales a distance that must not be overstated
+        p.pq_cell[k] = ctx->host.pq_inv[k] > 0.f ? static_cast<float>((1.0 / static_cast<double>(ctx->host.pq_inv[k])) * 0.9999) : 0.f;
     }
     p.pq_cell_count = static_cast<int32_t>(ctx->host.pq_cells.size());
     p.pq_list_count = static_cast<int32_t>(ctx->host.pq_list.size());
@@ -602,6 +605,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
                      ctx->host.spheres.size() == ctx->host.prims.size()) ? 1 : 0;
     p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
     p.lds_fill = static_cast<int32_t>(ctx->opt_lds_fill);
+    p.multi_step = static_cast<int32_t>(ctx->opt_multi_step);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2 &&
         ctx->host.spheres.size() <= 256) {  // one radius, bit for bit; at most 256 spheres: the scan keys carry the id in eight bits
@@ -1319,6 +1323,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_lds_kb = value;
         return RM_OK;
     }
+    if (!std::strcmp(key, "multi_step")) {
+        ctx->opt_multi_step = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "lds_fill")) {
         ctx->opt_lds_fill = value ? 1 : 0;
         return RM_OK;
@@ -1422,6 +1430,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
+    else if (!std::strcmp(key, "multi_step")) *value = ctx->opt_multi_step;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;
     else if (!std::strcmp(key, "blocks_per_cu")) *value = ctx->opt_blocks_per_cu;

@@ -391,32 +391,42 @@ struct NormalAux {
     int k1;
     float lb2;
     uint32_t found;
+    float rho;       // every point within rho (per axis) of q lies in exactly those of the cell's LISTED leaves that q lies in (0: unknown)
+    float rho_cell;  // every point within rho_cell (per axis) of q is covered by the leaf list of q's cell: the host grows every
+                     // cell's list by 0.0101 (RM_NRM_DELTA and a margin), plus q's own distance to the faces of its cell
     bool ok;
 };
 // The three offset points of getNormal (raymarcher.ts:126-132) are hit - 0.01 e_i, stored as binary32:
 // |q_i - hit| <= 0.01 + half an ulp of a coordinate (< 2^-21 for |x| < 16); the box faces compared against are
-// binary32 and lo - delta / hi + delta round once more.  0.010003 covers all of it with a factor of 100 to spare.
+// binary32.  0.010003 covers all of it with a factor of 100 to spare.
 #define RM_NRM_DELTA 0.010003f
-// true when "box contains q" has the same answer for every point within RM_NRM_DELTA of p along one axis: p is outside by
-// more than delta on some axis, or inside by more than delta on all three
-__device__ __forceinline__ bool box_answer_is_stable(const float lo[3], const float hi[3], const Vec3f &p) {
-    const float d = RM_NRM_DELTA;
-    const bool far_out = p.x < lo[0] - d || p.x > hi[0] + d || p.y < lo[1] - d || p.y > hi[1] + d || p.z < lo[2] - d || p.z > hi[2] + d;
-    const bool deep_in = p.x >= lo[0] + d && p.x <= hi[0] - d && p.y >= lo[1] + d && p.y <= hi[1] - d && p.z >= lo[2] + d && p.z <= hi[2] - d;
-    return far_out || deep_in;
+// BoundingBox.contains (boundingBox.ts:15-21) and how far the answer is from changing, in one value: m = the smallest of
+// the six binary32 differences p - lo, hi - p.  A difference of two binary32 numbers has the sign of the real difference
+// and is zero only for equal operands (denormals are kept: float_denorm_mode_32 = 3), so  contains(p) <=> m >= 0  exactly
+// as the six inclusive compares decide it; and every point within |m| of p per axis gets the same answer (inside by m on
+// every axis, or outside by |m| on the axis that gives the minimum).  Nine instructions instead of six compares and five
+// mask operations -- and the stability radius of the leaf set, which the fused normal and the in-round march steps of
+// render_kernel_v2 need, comes with it.
+__device__ __forceinline__ float box_margin(const float lo[3], const float hi[3], const Vec3f &p) {
+    const float a = __builtin_fminf(__builtin_fminf(p.x - lo[0], p.y - lo[1]), p.z - lo[2]);
+    const float b = __builtin_fminf(__builtin_fminf(hi[0] - p.x, hi[1] - p.y), hi[2] - p.z);
+    return __builtin_fminf(a, b);
 }
 
-template <bool UR, bool NRM = false>
+template <bool UR>
 __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S, bool need, const Vec3f &q,
                                     uint32_t &count, int lane, bool coop, bool filter, bool use_grid,
-                                    unsigned long long *dbg_fallback_cycles, NormalAux *aux = nullptr) {
-    if (NRM) aux->ok = false;
+                                    unsigned long long *dbg_fallback_cycles, NormalAux *aux) {
+    aux->ok = false;
+    aux->rho = 0.f;
+    aux->rho_cell = 0.f;
     if (!filter) return bvh_distance_wave_seq(P, S, need, q, count, lane, coop, filter, use_grid, dbg_fallback_cycles);
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     bool walk_tree = false;
     bool in_root = false;
-    bool stable = true;  // NRM: the leaf set is the same within RM_NRM_DELTA of q
+    float rho = __builtin_inff();  // the leaf set is the same within rho of q (per axis): min |box_margin| over the root and the cell's leaves
+    float rho_cell = 0.f;
     BestScan bs;
     bs.k1 = -1;
     bs.hi1 = bs.lb1 = bs.lb2 = __builtin_inff();
@@ -432,14 +442,22 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
     };
     if (need && use_grid) {
         const RmBvhNode root = S.nodes[0];
-        if (box_contains(root.lo, root.hi, q)) {
-            const int cx = min(max(static_cast<int>((q.x - P.pq_origin[0]) * P.pq_inv[0]), 0), P.pq_dim[0] - 1);
-            const int cy = min(max(static_cast<int>((q.y - P.pq_origin[1]) * P.pq_inv[1]), 0), P.pq_dim[1] - 1);
-            const int cz = min(max(static_cast<int>((q.z - P.pq_origin[2]) * P.pq_inv[2]), 0), P.pq_dim[2] - 1);
+        const float m_root = box_margin(root.lo, root.hi, q);
+        if (m_root >= 0.f) {
+            const float gx = (q.x - P.pq_origin[0]) * P.pq_inv[0], gy = (q.y - P.pq_origin[1]) * P.pq_inv[1], gz = (q.z - P.pq_origin[2]) * P.pq_inv[2];
+            const int cx = min(max(static_cast<int>(gx), 0), P.pq_dim[0] - 1);
+            const int cy = min(max(static_cast<int>(gy), 0), P.pq_dim[1] - 1);
+            const int cz = min(max(static_cast<int>(gz), 0), P.pq_dim[2] - 1);
             in_root = true;
-            // (RM_NRM_DELTA's margin assumes half an ulp of a coordinate below 2^-21: |coordinate| < 16)
-            if (NRM) stable = box_answer_is_stable(root.lo, root.hi, q) &&
-                              __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)), __builtin_fabsf(q.z)) < 16.0f;
+            {   // how far q is from the faces of its cell, in world units (the cell coordinates carry ~1e-5 of a cell of
+                // rounding: the 1e-4 the host's 0.0101 has over the 0.0100 used here covers it forty times)
+                const float fx = gx - static_cast<float>(cx), fy = gy - static_cast<float>(cy), fz = gz - static_cast<float>(cz);
+                const float in_cell = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, 1.0f - fx) * P.pq_cell[0], __builtin_fminf(fy, 1.0f - fy) * P.pq_cell[1]),
+                                                      __builtin_fminf(fz, 1.0f - fz) * P.pq_cell[2]);
+                rho_cell = 0.0100f + __builtin_fmaxf(in_cell, 0.f);
+            }
+            // (the margins of RM_NRM_DELTA assume half an ulp of a coordinate below 2^-21: |coordinate| < 16)
+            rho = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)), __builtin_fabsf(q.z)) < 16.0f ? m_root : 0.f;
             const uint32_t cell = S.pq_cells[(cz * P.pq_dim[1] + cy) * P.pq_dim[0] + cx];
             const int ccnt = static_cast<int>(cell & 0xFFu);
             if (ccnt == 255) walk_tree = true;  // crowded cell: the tree walk below
@@ -448,14 +466,15 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
                 for (int e = 0; e < ccnt; ++e) {
                     RM_CNT(7)
                     const RmBvhNode node = S.nodes[lst[e]];
-                    if (NRM) stable = stable && box_answer_is_stable(node.lo, node.hi, q);
-                    if (box_contains(node.lo, node.hi, q)) scan_leaf(node);
+                    const float m = box_margin(node.lo, node.hi, q);
+                    rho = __builtin_fminf(rho, __builtin_fabsf(m));
+                    if (m >= 0.f) scan_leaf(node);
                 }
             }
         }
     }
     if (need && (!use_grid || walk_tree)) {
-        stable = false;  // the fused normal evaluation relies on the cell's leaf list (grown by RM_NRM_DELTA on the host)
+        rho = 0.f;  // the fused normal evaluation and the in-round steps rely on the cell's leaf list (grown by RM_NRM_DELTA on the host)
         int i = 0;
         const int n = S.bvh_nodes;
         while (i < n) {  // BVH.getPrimitivesAt (bvh.ts:95-121), stackless
@@ -504,11 +523,13 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
         if (closest > RM_MAX_DIST) closest = RM_MAX_DIST;  // Math.min(sdf, closestDistance = 10)
         redo = bs.lb2 <= f32_upper_bound(closest);
     }
-    if (NRM) {  // the value came from sphere k1 alone, every other candidate of the (stable) leaf set is at least lb2 away
+    {   // the value came from sphere k1 alone, every other candidate of the leaf set (the same within rho) is at least lb2 away
         aux->k1 = bs.k1;
         aux->lb2 = bs.lb2;
         aux->found = found;
-        aux->ok = need && stable && in_root && found > 0 && bs.k1 >= 0 && !redo;
+        aux->rho = rho;
+        aux->rho_cell = rho_cell;
+        aux->ok = need && in_root && found > 0 && bs.k1 >= 0 && !redo;
     }
     if (__any(redo)) {  // near tie somewhere in the wave: those lanes take the sequential form (same result by construction)
         if (redo) RM_CNT(11)
@@ -1288,16 +1309,16 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
         aux.k1 = 0;
         aux.lb2 = 0.f;
         aux.found = 0;
+        aux.rho = 0.f;
+        aux.rho_cell = 0.f;
         if (ACCEL == 2) {
 #ifdef RM_STAMPS
             unsigned long long fbc = 0;
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, &fbc, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, &fbc);
+            dist = bvh_distance_wave<UR>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, &fbc, &aux);
             t_acc_[4] += fbc;
             t_prev_ += fbc;  // keep section 2 = query + leaf evaluation only
 #else
-            if (n0_go) dist = bvh_distance_wave<UR, true>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, nullptr, &aux);
-            else dist = bvh_distance_wave<UR, false>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, nullptr);
+            dist = bvh_distance_wave<UR>(CB, SB, need, q, evaluated, lane_b, coop, filter, use_grid, nullptr, &aux);
 #endif
         }
         else if (ACCEL == 1) dist = need ? oct_distance_lane(SB, onode, q, evaluated, filter) : RM_MAX_DIST;
@@ -1309,7 +1330,8 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
 
         RM_T(2)
         // ---- C: consume -------------------------------------------------------------------------
-        const bool fuse = ACCEL == 2 && need && (st & ST_PHASE) == PH_N0 && aux.ok;
+        const bool fuse = ACCEL == 2 && need && (st & ST_PHASE) == PH_N0 && aux.ok && aux.rho > RM_NRM_DELTA;
+        const bool was_marching = need && (st & ST_PHASE) == PH_MARCH;
         if (need) {
             const int ph = st & ST_PHASE;
             if (ph == PH_MARCH) {
@@ -1330,6 +1352,53 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                 normalize3(nx, ny, nz);
                 set_normal(nx, ny, nz);
                 set_phase(PH_DONE);
+            }
+        }
+        // ---- M: more march steps inside this round (sphereTracer.ts:43-75, bvh.ts:204-240, scene.ts:167-181), for as long as
+        // they provably see what this round saw.  A ray close to a surface takes step after step against the same sphere: a
+        // ray that grazes one takes up to a hundred, each a whole round of the wave loop with one or two lanes at work --
+        // the slowest rays of a batch set its number of rounds.  The next step is taken HERE, by the lane alone, when
+        //  * the march goes on (trip count, epsilon and MAX_DIST tests as the loop makes them) and the point's parameter
+        //    lies inside the current interval, so that onRayMarchStep answers 0 without touching its state;
+        //  * the new point p2 is within rho of this round's point q (distance measured between the two binary32 points,
+        //    rounded up), rho being the stability radius of the leaf set (box_margin of every leaf the cell lists, and not
+        //    beyond what that list covers: the cell grown by 0.0100): getPrimitivesAt returns the same leaves, the counter
+        //    advances by the same `found`;
+        //  * every other candidate, at least lb2 away at q and 1-Lipschitz, is still farther at p2 than the exact
+        //    distance of the sphere k1 that won at q: Math.min over the candidates is that distance.
+        // The step is then exactly the one the ordinary path would take (same point, same value, same counters); a lane
+        // that fails a test has committed nothing of that step and takes it in the next round.
+        if (ACCEL == 2 && CB.multi_step) {
+            const bool go = was_marching && aux.ok && (st & ST_PHASE) == PH_MARCH;
+            if (__any(go)) {
+                if (go) {
+                    const SceneView SM = scene_view<ACCEL, LDS, REL>(cold_params(), smem);
+                    const RmSphere s1 = SM.spheres[aux.k1];
+                    const double r1 = SM.radii[aux.k1];
+                    const float rho = __builtin_fminf(aux.rho, aux.rho_cell);
+                    for (;;) {
+                        if ((st & ST_TRIP_MASK) >= (RM_MAX_STEPS << ST_TRIP_SHIFT)) {  // loop exhausted: return totalDist
+                            finish_march(t);
+                            break;
+                        }
+                        if (t < sA || t > sB) break;  // the interval state machine has work to do: the ordinary path
+                        const Vec3f p2 = point_at(ray, t);
+                        const float ex = p2.x - q.x, ey = p2.y - q.y, ez = p2.z - q.z;
+                        const float dd = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.00001f + 1e-7f;  // >= |p2 - q|
+                        if (!(dd < rho)) break;
+                        const double e = sphere_sdf_fast(s1, r1, p2);
+                        if (!(aux.lb2 - dd > f32_upper_bound(e))) break;
+                        RM_CNT(15)
+                        st += 1 << ST_TRIP_SHIFT;
+                        counters += (aux.found << 16) + 1u;
+                        const double d2 = __builtin_fmin(e, RM_MAX_DIST);  // Math.min(sdf, closestDistance = 10)
+                        t += d2;
+                        if (d2 < RM_EPSILON || t > RM_MAX_DIST) {
+                            finish_march(t);
+                            break;
+                        }
+                    }
+                }
             }
         }
         // ---- N: the three offset samples of getNormal (raymarcher.ts:126-132) from the sphere that gave d0.  The leaf

@@ -134,6 +134,7 @@ struct RmRenderParams {
     int32_t use_grid;
     float pq_origin[3];
     float pq_inv[3];
+    float pq_cell[3];          // cell size of the point-query grid per axis, rounded DOWN (1 / pq_inv: rm_render_v2.hip rho_cell)
     int32_t refill_threshold;  // v2: idle lanes that trigger a ballot/prefix refill (64 = whole wave)
     int32_t hw_xcd;            // v2: read the XCD id from HW_REG_XCC_ID instead of blockIdx % 8
     int32_t item_px;           // v2: pixels per work item (64, 128, 256)
@@ -205,7 +206,8 @@ struct RmRenderParams {
     // Fused diagnostics (rm_diag.h; main.ts:528-548): the launch's accumulator block (from a ring in rm_api.cpp; all zero
     // before and after the launch) and where the launch's last wave writes the 32-byte result (null: no diagnostics).
     // v2 launches always carry a block: the last wave also re-zeroes the launch's tile-queue heads.
-    int32_t lds_fill, lds_fill_pad;  // v2: option `lds_fill` (rm_render_v2.hip: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU)
+    int32_t lds_fill;    // v2: option `lds_fill` (rm_render_v2.hip: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU)
+    int32_t multi_step;  // v2 BVH: march steps inside a round while the leaf set and the winning sphere provably stay the same (option `multi_step`)
     RmDiagBlock *diag_block;
     RmDiagDevice *diag_out;
 };

@@ -33,7 +33,7 @@ N.lib().rm_debug_read_counts(ctx._h, out.ctypes.data_as(C.c_void_p))
 names = ["wave-loop iteration", "R refill section", "A march-step bookkeeping pass", "A bvh_next call", "A bvh_next list entry",
          "R prologue node visit", "B getDistance", "B cell leaf-list entry", "B leaf sphere scan", "B nn-list sphere scan",
          "B exact evaluation", "B near-tie redo", "B cooperative fallback ray", "B fallback not served by nn", "A normal sample",
-         "R ray setup + prologue"]
+         "M in-round march step"]
 print("%-32s %12s %14s %6s %10s" % ("event", "wave execs", "lanes", "util", "lanes/px"))
 for i, n in enumerate(names):
     w, l = int(out[i]), int(out[i + 16])

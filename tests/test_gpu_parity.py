@@ -100,10 +100,11 @@ def test_v1_and_v2_kernels_agree(rm, oracle):
                      dict(kernel=2, lds_kb=64, rel=0), dict(kernel=2, cull=0), dict(kernel=2, cull=0, rel=0),
                      dict(kernel=2, n0_batch=1), dict(kernel=2, n0_batch=16, refill=24), dict(kernel=2, n0_batch=8, uniform=0, cull=0),
                      dict(kernel=2, lpt=0), dict(kernel=2, lpt=1), dict(kernel=2, lpt=1, item_px=64, tile_w=32),
+                     dict(kernel=2, multi_step=0), dict(kernel=2, multi_step=0, uniform=0, rel=0), dict(kernel=2, multi_step=1, n0_batch=8, refill=24),
                      dict(kernel=1, oct_lean=0), dict(kernel=1, oct_lean=0, v1_block=256, tile_w=16), dict(kernel=1, v1_block=128, tile_w=32)]:
             for k, v in dict(kernel=2, coop=1, filter=1, nodes_in_lds=1, list_cap=32, tile_w=8, grid=1, refill=64,
                              hw_xcd=1, blocks_per_cu=3, recs=1, lut=1, nn=2, sub=1, item_px=128, static=0, uniform=1, rel=1, lds_kb=0, cull=1,
-                             n0_batch=64, lpt=1, oct_lean=1, v1_block=64).items():
+                             n0_batch=64, lpt=1, oct_lean=1, v1_block=64, multi_step=1).items():
                 ctx.set_option(k, v)
             for k, v in opts.items():
                 ctx.set_option(k, v)

@@ -72,7 +72,7 @@ struct rm_ctx {
     RmDiagDevice *d_diag = nullptr;
     float light[3] = {0, 0, 0};
 
-    int64_t opt_tile_w = 16;
+    int64_t opt_tile_w = 8;  // 8 x 8-pixel batches (a frame alone, round 3: 128-pixel items of 8 x 16: 1.09 ms; of 16 x 8: 1.17 ms)
     bool tile_w_set = false;  // rm_set_option("tile_w") was called: the value then holds for every kernel (else v1 kernels use 8 x 8 wave tiles)
     int64_t opt_filter = 1;
     int64_t opt_lds = 1;
@@ -98,7 +98,8 @@ struct rm_ctx {
     int64_t opt_v1_lists = 1;  // v1 BVH kernels: per-ray hit-leaf lists instead of one tree walk per interval advance
     int64_t opt_v1_block = 64;  // v1 kernels: threads per workgroup (one wave: wave slots refill one by one)
     int64_t opt_oct_lean = 1;  // octree, sphere scenes, sphere tracer: render_kernel_oct (rm_kernels.hip) instead of render_kernel<1, false, 0>
-    int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's costs (shortens the tail of a frame that runs alone)
+    int64_t opt_lpt = 0;  // v2: longest-first item order from the previous frame's costs.  Off since round 3: with the in-round march steps a
+                          // frame's slowest items are no longer slow enough to pay for the sort launch (alone 1.12 ms without, 1.17 ms with)
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
     // permutation and records its own costs); geometry changes restart the feedback
     static constexpr int kLptSlots = 16;
@@ -555,9 +556,10 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     p.nodes_in_lds = static_cast<int32_t>(ctx->opt_lds);
     p.filter = static_cast<int32_t>(ctx->opt_filter);
     p.variant = static_cast<int32_t>(ctx->opt_kernel);
-    // auto: the octree and small scenes (the 9-sphere grid: 0.59 ms against 0.75 ms at 1080p) run faster in the
-    // one-ray-per-lane kernel; the uniform wave loop pays off when leaves and fallbacks are expensive
-    if (p.variant == 0) p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 24) ? 1 : 2;
+    // auto: the octree runs in the one-ray-per-lane kernels; so do the smallest scenes.  (Until round 2 the 9-sphere grid of C2
+    // was faster there too; since the in-round march steps of round 3 the uniform wave loop wins it: 0.308 against 0.331 ms
+    // alone, 9 680 against 8 920 frames/s in flight.)
+    if (p.variant == 0) p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 8) ? 1 : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
     if (ctx->host.general) p.variant = 1;                    // so do boxes, tori and rotated primitives
     // v1: square 8 x 8 wave tiles keep a wave's rays in the same leaves / intervals (N3-mixed 2.31 -> 2.07 ms together with

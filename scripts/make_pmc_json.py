@@ -1,4 +1,4 @@
-"""Digest of a scripts/profile_r02.sh capture -> profiles/r02/pmc_<workload>.json (what bench.py reads for
+"""Digest of a scripts/profile_round.sh capture -> profiles/<round>/pmc_<workload>.json (what bench.py reads for
 roofline.traffic and roofline.valu) and pmc_<workload>.txt (the per-kernel tables a reader can recompute from).
 
   traffic_bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 per render-kernel launch (rocprofv3 reports KB; separate passes).
@@ -51,8 +51,11 @@ def main():
             options[k] = int(v)
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:  # noqa: BLE001 -- the GPU box has no .git
-        commit = None
+    except Exception:  # noqa: BLE001 -- the GPU box has no .git: scripts/gpu_battery.sh leaves the commit in .build_commit
+        try:
+            commit = open(os.path.join(ROOT, ".build_commit")).read().strip() or None
+        except OSError:
+            commit = None
     res = {"workload": wl, "source_sha16": bench.kernel_source_hash(), "commit_at_capture": commit, "options": options,
            "bench_args": " ".join(args), "kernel": kernel_name, "kernel_ms_rocprof": kernel_ms, "launches_counted": launches,
            "counters_per_launch": {k: counters[k] for k in sorted(counters)}}
@@ -61,12 +64,13 @@ def main():
         res["traffic_bytes"] = int(round((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024))
     # the `valu` block (mix priced with the measured issue costs) is added by scripts/price_valu.py in the build container,
     # where the kernel's .s listing is at hand
-    dst = os.path.join(ROOT, "profiles", "r02")
+    rnd = os.environ.get("RM_ROUND", "r03")
+    dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     with open(os.path.join(dst, "pmc_%s.json" % wl), "w") as f:
         json.dump(res, f, indent=1)
     with open(os.path.join(dst, "pmc_%s.txt" % wl), "w") as f:
-        f.write("# %s  (scripts/profile_r02.sh; bench.py %s)\n" % (wl, " ".join(args)))
+        f.write("# %s  (scripts/profile_round.sh; bench.py %s; commit %s)\n" % (wl, " ".join(args), commit))
         f.write("== kernel stats (rocprofv3 --kernel-trace --stats)\n")
         for r in kstats:
             f.write("%-90s calls %-5s avg_ns %-12s total_ns %-12s pct %s\n" % (r.get("Name", "")[:90], r.get("Calls"), r.get("AverageNs"),
@@ -75,9 +79,9 @@ def main():
         for k in sorted(counters):
             f.write("%-28s %16.6g\n" % (k, counters[k]))
     # gpurun merges gpurun_out back; profiles/ written on the GPU box is lost unless copied there too
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles_r02"), exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles_" + rnd), exist_ok=True)
     for n in ("pmc_%s.json" % wl, "pmc_%s.txt" % wl):
-        with open(os.path.join(dst, n)) as a, open(os.path.join(ROOT, "gpurun_out", "profiles_r02", n), "w") as b:
+        with open(os.path.join(dst, n)) as a, open(os.path.join(ROOT, "gpurun_out", "profiles_" + rnd, n), "w") as b:
             b.write(a.read())
     print(json.dumps({k: res.get(k) for k in ("workload", "kernel", "kernel_ms_rocprof", "traffic_bytes")}))
 

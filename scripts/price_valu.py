@@ -1,8 +1,8 @@
-"""Adds the `valu` block to profiles/r02/pmc_<workload>.json: the render kernel's measured VALU instruction mix priced
+"""Adds the `valu` block to profiles/<round>/pmc_<workload>.json: the render kernel's measured VALU instruction mix priced
 with the issue costs measured on this chip ("measure the real VALU ceiling").
 
-  counts   SQ_INSTS_VALU and the SQ_INSTS_VALU_* buckets per launch (rocprofv3, scripts/profile_r02.sh)
-  costs    profiles/r02/valu_issue_costs.json (scripts/valu_issue_bench): cycles one wave64 instruction costs a SIMD with
+  counts   SQ_INSTS_VALU and the SQ_INSTS_VALU_* buckets per launch (rocprofv3, scripts/profile_round.sh)
+  costs    profiles/<round>/valu_issue_costs.json (scripts/valu_issue_bench): cycles one wave64 instruction costs a SIMD with
            five waves resident = the slowest wave's cycles / (instructions x 5)  [the mean over waves is lower only
            because waves that start late run part of the time with fewer than five on the SIMD]
   OTHER    = SQ_INSTS_VALU - sum(buckets): compares, selects, min / max, moves, lane reads ... have no PMC bucket.
@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cpu_raymarcher_amd", "csrc")
-PROF = os.path.join(ROOT, "profiles", "r02")
+PROF = os.path.join(ROOT, "profiles", os.environ.get("RM_ROUND", "r03"))
 
 # mnemonic (regex) -> (PMC bucket or OTHER, measured class in valu_issue_costs.json)
 RULES = [
@@ -85,7 +85,9 @@ def static_mix(kernel_demangled):
 def main():
     costs = json.load(open(os.path.join(PROF, "valu_issue_costs.json")))
     cls = costs["classes"]
-    W = "w5"
+    # waves per SIMD the kernel runs at: v2 kernels six (round 3), the lean octree kernel eight (priced at the most the
+    # micro-benchmark measures: six)
+    W = "w6" if "w6" in next(iter(cls.values())) else "w5"
     cyc = lambda n: cls[n][W]["cycles_slowest_wave"]  # noqa: E731
     clock = sorted(v[W]["clock_mhz"] for v in cls.values())[len(cls) // 2]
     simds = costs["compute_units"] * 4
@@ -124,11 +126,11 @@ def main():
             "insts": total, "by_class": by, "cycles_per_inst": cpi, "issue_cycles_by_class": {b: by[b] * cpi[b] for b in by},
             "weighted_issue_floor_ms": floor_ms, "kernel_ms_rocprof": pj.get("kernel_ms_rocprof"),
             "frac_of_kernel_alone": floor_ms / pj["kernel_ms_rocprof"] if pj.get("kernel_ms_rocprof") else None,
-            "lane_util": lane_util, "waves_per_simd_priced": 5, "clock_mhz": clock, "simds": simds,
+            "lane_util": lane_util, "waves_per_simd_priced": int(W[1:]), "clock_mhz": clock, "simds": simds,
             "salu_insts": c.get("SQ_INSTS_SALU"), "lds_insts": c.get("SQ_INSTS_LDS"),
             "other_static_top": dict(other_detail.most_common(12)), "static_listing": listing,
-            "source": "SQ_INSTS_VALU_* per launch (rocprofv3) x profiles/r02/valu_issue_costs.json (cycles_slowest_wave at 5 waves per "
-                      "SIMD); per-bucket costs weighted by the kernel's STATIC mnemonic mix (%s)" % listing}
+            "source": "SQ_INSTS_VALU_* per launch (rocprofv3) x profiles/<round>/valu_issue_costs.json (cycles_slowest_wave at %s waves per "
+                      "SIMD); per-bucket costs weighted by the kernel's STATIC mnemonic mix (%s)" % (W[1:], listing)}
         json.dump(pj, open(path, "w"), indent=1)
         print("%s: %.3g VALU insts, issue floor %.3f ms vs kernel alone %.3f ms (%.0f %%), lane util %.1f %%; cycles/inst %s"
               % (wl, total, floor_ms, pj.get("kernel_ms_rocprof") or 0, 100 * floor_ms / (pj.get("kernel_ms_rocprof") or 1),

@@ -2,15 +2,17 @@
 # rocprofv3 capture of ONE workload's render kernel, serial launches with the library's default options
 # (bench.py --frames-in-flight 1): kernel trace + stats, then PMC passes, each alone and never with sys / hip traces
 # (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).  The program follows `--` directly.
-# usage: scripts/profile_r02.sh <workload> [bench args...]   -> gpurun_out/prof_r02_<workload>/, digested by
-#        scripts/make_pmc_json.py into profiles/r02/pmc_<workload>.json + pmc_<workload>.txt
+# usage: scripts/profile_round.sh <workload> [bench args...]   -> gpurun_out/prof_<round>_<workload>/, digested by
+#        scripts/make_pmc_json.py into profiles/<round>/pmc_<workload>.json + pmc_<workload>.txt   (RM_ROUND, default r03)
 set -e
 WL=${1:-C3}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r02_$WL
+RND=${RM_ROUND:-r03}
+export RM_ROUND=$RND
+OUT=$R/gpurun_out/prof_${RND}_$WL
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $WL --frames-in-flight 1 --steps 6 --warmup 2 --no-cpu-baseline $@"
+ARGS="--workload $WL --frames-in-flight 1 --steps 6 --warmup 2 --no-cpu-baseline --no-verify $@"
 echo "$ARGS" > $OUT/bench_args.txt
 run() {  # name, rocprofv3 args...
   local name=$1; shift

@@ -2,14 +2,14 @@
 //
 // VERDICT r1 asked for the measured VALU ceiling of the render kernel instead of an assumed "4 cycles per wave
 // instruction".  This micro-benchmark issues long runs of independent instructions of ONE class from W waves per SIMD
-// (W = 1, 2, 5: the render kernel runs at 5) on every SIMD of the chip and reports
+// (W = 1, 2, 5, 6: the render kernel ran at 5 in rounds 1-2, runs at 6 since round 3) on every SIMD of the chip and reports
 //     cycles per wave-instruction per SIMD = wave's elapsed shader cycles (s_memtime) / (instructions x W),
 // the wall-clock rate, and the shader clock (s_memtime ticks / wall time).  The render kernel's instruction mix
 // (rocprofv3 SQ_INSTS_VALU_* counters) priced with these costs is the "weighted issue floor" in bench.py's
 // roofline.valu block (scripts/make_pmc_json.py).
 //
 // build: hipcc --offload-arch=gfx950 -O2 -o scripts/bin/valu_issue_bench scripts/valu_issue_bench.hip
-// run:   scripts/bin/valu_issue_bench > profiles/r02/valu_issue_costs.json
+// run:   scripts/bin/valu_issue_bench > profiles/r03/valu_issue_costs.json
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -291,7 +291,7 @@ int main(int argc, char **argv) {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount;
-    const int max_w = 5;
+    const int max_w = 6;
     (void)argc; (void)argv;
     Result *d_out;
     CHECK(hipMalloc(&d_out, sizeof(Result) * cus * max_w * 4 + 4096));
@@ -308,10 +308,11 @@ int main(int argc, char **argv) {
         printf("%s  \"%s\": {\"pmc_class\": \"%s\"", first ? "" : ",\n", en.name, en.pmc_class);
         first = false;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(en.k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        for (int w : {1, 2, 5}) {
+        for (int w : {1, 2, 5, 6}) {
             const int blocks = cus * w;  // one 4-wave workgroup per CU and per wave-per-SIMD
             // dynamic LDS so that exactly w workgroups fit a CU's 160 KB: the dispatcher cannot pile 8 on one CU
-            const size_t lds = w == 1 ? 96 * 1024 : (w == 2 ? 64 * 1024 : 32 * 1024 - 1024);
+            // (LDS is handed out in granules of 1 280 bytes: 31 744 -> 32 000 x 5 = 160 000; 26 624 -> 26 880 x 6 = 161 280 <= 163 840)
+            const size_t lds = w == 1 ? 96 * 1024 : (w == 2 ? 64 * 1024 : (w == 5 ? 32 * 1024 - 1024 : 26 * 1024));
             hipLaunchKernelGGL(en.k, dim3(blocks), dim3(256), lds, 0, d_out, 1.5f, 0);  // warm-up
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0, 0));

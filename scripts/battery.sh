@@ -53,3 +53,4 @@ if [ "$1" != quick ]; then
   grep -v amdgpu.ids $P/shard_overhead.txt
 fi
 cp -r $P/* $O/ 2>/dev/null || true
+rm -f $O/*.err.copy 2>/dev/null || true

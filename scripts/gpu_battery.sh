@@ -10,5 +10,5 @@ hipcc_bin=/opt/rocm/bin/hipcc
 mkdir -p scripts/bin && $hipcc_bin --offload-arch=gfx950 -O2 -o scripts/bin/valu_issue_bench scripts/valu_issue_bench.hip 2> /dev/null
 /usr/local/graft/bin/gpurun --timeout 1150 -- "RM_ROUND=$RM_ROUND scripts/battery.sh $1 > gpurun_out/battery.log 2>&1; tail -40 gpurun_out/battery.log"
 mkdir -p profiles/$RM_ROUND
-cp gpurun_out/$RM_ROUND/* profiles/$RM_ROUND/ 2>/dev/null || true
+for f in gpurun_out/$RM_ROUND/*; do case $f in *.err) ;; *) cp $f profiles/$RM_ROUND/ ;; esac; done
 ls profiles/$RM_ROUND

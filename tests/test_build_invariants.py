@@ -79,3 +79,64 @@ def test_lean_octree_kernel_keeps_eight_waves_without_spills(extra):
     k = [r for n, r in usage.items() if n.startswith("render_kernel_oct(")]
     assert len(k) == 1, sorted(usage)
     assert k[0]["VGPRs Spill"] == 0 and k[0]["ScratchSize [bytes/lane]"] == 0 and k[0]["Occupancy [waves/SIMD]"] == 8, k[0]
+
+
+def listing(source, extra=()):
+    out = os.path.join("/tmp", "rm_inv_%d_%s.s" % (os.getpid(), os.path.basename(source)))
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
+                    "-mllvm", "-amdgpu-inline-max-bb=100000", "-o", out, os.path.join(CSRC, source), *extra],
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+    try:
+        return open(out).read().split("\n")
+    finally:
+        os.remove(out)
+
+
+def spill_code_ahead_of_exec_restore(lines):
+    """The code-generation defect behind round 2's wrong pixels (profiles/r03/spill_exec_hazard.txt): hipcc 7.2 placed a
+    folded VGPR spill at the top of a JOIN block, ahead of the s_or_b64 exec that re-enables the lanes which skipped the
+    branch -- those lanes never wrote the spill slot and reloaded garbage later.  Returns the (line number, text) of every
+    folded VGPR spill / reload that sits between a block label and an EXEC-widening instruction of the same block."""
+    bad, pending, whole_wave = [], [], False
+    for n, raw in enumerate(lines):
+        t = raw.strip()
+        if not t or t.startswith((";", "//")):
+            continue
+        if t.endswith(":") or t.startswith(".LBB") or t.startswith("; %bb."):  # a new block: nothing pending carries over
+            pending, whole_wave = [], False
+            continue
+        if t.startswith("."):
+            continue
+        op = t.split()[0]
+        # (a function's prologue / epilogue saves its callee-saved VGPRs in whole-wave mode: s_or_saveexec_b64 sN, -1 ... spill ...
+        # s_mov_b64 exec, sN.  There the spill runs with EVERY lane enabled and the following write of EXEC narrows: correct.)
+        if re.match(r"(s_or_saveexec_b64\s+\S+,\s*-1|s_mov_b64\s+exec,\s*-1)", t):
+            whole_wave = True
+            continue
+        if op.startswith("scratch_") and "Folded" in t:
+            if not whole_wave:
+                pending.append((n + 1, t))
+            continue
+        if whole_wave and re.match(r"\S+\s+exec\b", t):
+            whole_wave = False
+            continue
+        widens = (op in ("s_or_b64", "s_mov_b64", "s_or_saveexec_b64", "s_xor_b64", "s_orn2_b64") and re.match(r"\S+\s+exec\b", t) is not None)
+        if widens and pending:
+            bad.extend(pending)
+            pending = []
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            pending = []
+    return bad
+
+
+def test_the_scanner_finds_the_round_2_pattern():
+    sample = [".LBB3_549:", "\tscratch_store_dword off, v49, off offset:136 ; 4-byte Folded Spill", "\ts_or_b64 exec, exec, s[0:1]",
+              "\tv_mov_b32_e32 v0, 0", ".LBB3_550:", "\ts_or_b64 exec, exec, s[2:3]", "\tscratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload"]
+    assert [n for n, _ in spill_code_ahead_of_exec_restore(sample)] == [2]
+
+
+@pytest.mark.parametrize("source,extra", [("rm_render_v2.hip", ()), ("rm_render_v2.hip", ("-DRM_LENGTH_SQRT",)), ("rm_kernels.hip", ()),
+                                          ("rm_kernels.hip", ("-DRM_LENGTH_SQRT",))])
+def test_no_spill_code_ahead_of_an_exec_restore(source, extra):
+    bad = spill_code_ahead_of_exec_restore(listing(source, extra))
+    assert not bad, bad[:5]

@@ -810,6 +810,21 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
                         t += step + 0.001;
                         if (t > RM_MAX_DIST) phase = PH_DONE;  // `break`: depth >= MAX_DIST, no normal
                         evaluated = false;                      // `continue`
+                        // Skip chain: a skip that minDistance cut short leaves the ray INSIDE this empty leaf, and the next trips of
+                        // the reference's loop find the same node and compute the same tExit -- only t differs.  While the
+                        // new t is clearly short of tExit (by near_margin: the march point then lies inside the box by more than
+                        // its binary32 rounding on every axis, so findNode returns this leaf again, and tEnter, which only shrinks
+                        // relative to t, cannot exceed tExit), the next skip needs neither the cell table nor the node: it is
+                        // min(tExit - t, cap) + 0.001 again.  Each is a trip of the march loop (sphereTracer.ts:43,59-64).
+                        while (phase != PH_DONE && phase < (RM_MAX_STEPS << 3)) {
+                            const double ahead2 = static_cast<double>(xt) - t;
+                            if (!(ahead2 > near_margin)) break;
+                            RM_CNT1(3)
+                            phase += 8;
+                            const double step2 = ahead2 < cap ? ahead2 : cap;  // ahead2 > 0; cap > 0 (step > 0 above)
+                            t += step2 + 0.001;
+                            if (t > RM_MAX_DIST) phase = PH_DONE;
+                        }
                     }
                 }
                 if (evaluated) {

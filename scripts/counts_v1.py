@@ -34,7 +34,7 @@ R.SphereTracer().runRaymarcher(sc, d, nb, s, it, W, H, 0.0, shadedBuffer=rg, sha
 torch.cuda.synchronize()
 N.lib().rm_debug_read_counts(ctx._h, out.ctypes.data_as(C.c_void_p))
 print(ctx.last_kernel())
-names = ["march-loop iteration", "skip taken", "leaf evaluation (prims > 0)", "(bvh_next call)", "(bvh_next list entry)", "(prologue node visit)",
+names = ["march-loop iteration", "skip taken", "leaf evaluation (prims > 0)", "skip chained inside the same empty leaf", "(bvh_next list entry)", "(prologue node visit)",
          "scan trip: sub-cell candidate", "scan trip: 4 records of the full list", "exact evaluation", "near-tie rescan", "-",
          "empty node: minDistance", "outside the cube: all primitives", "getNormal (4 samples)", "wave start", "scan trip: full-list tail record"]
 print("%-40s %12s %14s %6s %10s %10s" % ("event", "wave execs", "lanes", "util", "lanes/px", "execs/wave"))

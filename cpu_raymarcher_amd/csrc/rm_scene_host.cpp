@@ -810,7 +810,11 @@ bool build_scene_general(HostScene &s, const PrimDesc *prims, int n, int accel, 
             bs.cy = l2w.m[13];
             bs.cz = l2w.m[14];
             // slack: the inverse's rounding (1e-6 relative on c), the 1e-6 orthonormality tolerance over the radius
-            bs.rf = std::nextafter(static_cast<float>(std::fabs(local_radius) * (1.0 + 3e-5) + 1e-5 * (1.0 + cabs)), INFINITY);
+            // (the torus: |p| - |a| - |b| <= sdf <= |p| + |a| + |b| for radii of either sign -- triangle inequality in the (r, y)
+            // plane; a + b, the reference's bounding-box radius kept in local_radius for prim_lo / prim_hi, is not a bound when a
+            // radius is negative: ADVICE r2)
+            const double bound_radius = (q.type & 0xFF) == 2 ? std::fabs(q.a) + std::fabs(q.b) : std::fabs(local_radius);
+            bs.rf = std::nextafter(static_cast<float>(bound_radius * (1.0 + 3e-5) + 1e-5 * (1.0 + cabs)), INFINITY);
             s.spheres.push_back(bs);
         }
     }

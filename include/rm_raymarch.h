@@ -352,12 +352,16 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *   uniform 0|1   scenes whose spheres share one radius: rank leaf candidates by squared centre distance (v2, default 1)
  *   rel 0|1       BVH node boxes relative to the frame's ray origin, as doubles in LDS, when they fit (v2, default 1)
  *   cull 0|1      whole 64-pixel batches find their hit BVH leaves by a bundle-frustum cull (v2, <= 256 leaves, default 1)
- *   lds_kb 16..64 LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (32: five workgroups per CU; 40: four)
+ *   lds_kb 0|16..64  LDS budget per workgroup the v2 launcher trims the per-ray hit lists to (0, default: as many workgroups per CU
+ *                 as the kernel's registers allow -- six, 26 880 bytes each --, then five, then four; 32: five; 40: four)
  *   n0_batch 1..64 BVH (v2): getNormal is deferred until no lane of the wave needs a march distance, then evaluated for all waiting
  *                 rays in one round, the three offset samples taken from the sphere that gave d0 where provably the minimum;
  *                 lanes waiting that trigger that round early (64: never early; default 64)
  *   lpt 0|1       v2: hand out a launch's work items longest-first using the item costs the previous launch recorded (any
- *                 order gives the same bytes; shortens the tail of a frame that runs alone; default 1)
+ *                 order gives the same bytes; default 0 since round 3: the in-round march steps took the slowest items' edge)
+ *   multi_step 0|1  v2 BVH: a lane takes further march steps inside a round while the leaf set and the winning sphere provably
+ *                 stay the same (default 1; same bytes either way)
+ *   lds_fill 0|1  v2: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU (default 0; measurement knob)
  *   v1_lists 0|1  v1 BVH kernels: per-ray hit-leaf lists (as v2) instead of one tree walk per interval advance (default 1)
  *   v1_block 64|128|256  v1 kernels: threads per workgroup (default 64: one wave, so wave slots refill one by one); without an
  *                 explicit tile_w the v1 kernels use 8 x 8-pixel wave tiles
@@ -368,7 +372,12 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *   length 0|1    gl-matrix vec3.length / vec3.distance (sphere.ts:12-14, box.ts:26,33, mandelbulb.ts:46, smoothUnion.ts:45):
  *                 0 = Math.hypot(x, y, z) (gl-matrix 3.0 - 3.4.3, default), 1 = Math.sqrt(x*x + y*y + z*z) (the form a later
  *                 3.4.x release may use).  Results differ by <= 1 ulp(f64) per distance; the active scene is
- *                 rebuilt (bounding radii of boxes and smooth unions use it too). */
+ *                 rebuilt (bounding radii of boxes and smooth unions use it too).
+ *                 NOTE: the reference pins gl-matrix 3.4.4 (package.json:25), whose source is not available offline, while the
+ *                 DEFAULT follows the formula of 3.0 - 3.4.3.  Nothing in the reference tree decides between the two (no
+ *                 fixture, no test): parity is unpinned on this point.  Goldens, the cross-check shim and the benchmark exist
+ *                 for both modes (tests/golden/, bench.py --opt length=1), so the default is a one-line change
+ *                 (rm_api.cpp: opt_length) once the pinned version's formula is known. */
 RM_API int rm_set_option(rm_ctx *ctx, const char *key, int64_t value);
 RM_API int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value);
 

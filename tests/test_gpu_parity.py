@@ -854,6 +854,44 @@ def test_golden_fixtures_at_baseline_sizes(rm, gpu_ctx, oracle, golden, golden_c
             assert hashlib.sha256(rgba.tobytes()).hexdigest() == g["sha256"]["rgba"], (name, "rgba")
 
 
+def test_bench_in_flight_configuration_at_4k(rm, golden):
+    """bench.py's TIMED configuration -- C3 at 3840x2160, twelve frames in flight on twelve streams, one
+    persistent workgroup per CU and launch, 256-pixel items of 8 x 32, no longest-first sort, the tail ramp (2, 3, 4
+    workgroups per CU for the last frames), diagnostics fused into the render kernel -- against the golden hashes of all
+    five buffers and the fixture's diagnostics, for every buffer set."""
+    import torch
+    W, H = 3840, 2160
+    dev = torch.device("cuda:0")
+    ctx = rm.Context(0)
+    for k, v in (("blocks_per_cu", 1), ("item_px", 256), ("tile_w", 8), ("lpt", 0)):
+        ctx.set_option(k, v)
+    scene = rm.Scene("BVH", ctx=ctx)
+    scene.loadPreset(3)
+    tracer = rm.SphereTracer()
+    S, steps = 12, 20
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    sets = [dict(depth=torch.zeros(W * H, dtype=torch.uint8, device=dev), normal=torch.zeros(3 * W * H, dtype=torch.uint8, device=dev),
+                 sdf=torch.zeros(W * H, dtype=torch.int16, device=dev), iters=torch.zeros(W * H, dtype=torch.int16, device=dev),
+                 rgba=torch.zeros(4 * W * H, dtype=torch.uint8, device=dev), acc=torch.full((4,), -1, dtype=torch.int64, device=dev))
+            for _ in range(S)]
+    for i in range(steps):
+        remaining = steps - 1 - i
+        ctx.set_option("blocks_per_cu", max(1, min(4, 4 - remaining)) if remaining < 4 else 1)  # bench.py --tail-ramp 4
+        b = sets[i % S]
+        with torch.cuda.stream(streams[i % S]):
+            tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0, shadedBuffer=b["rgba"],
+                                 shader="iteration-heatmap", diagnostics=b["acc"])
+    torch.cuda.synchronize()
+    assert "render_kernel_v2<2, true, true, false>" in ctx.last_kernel()
+    g = golden["C3_dense_4k_bvh_iterheat"]
+    for k, b in enumerate(sets):
+        for name in ("depth", "normal", "sdf", "iters", "rgba"):
+            assert hashlib.sha256(b[name].cpu().numpy().tobytes()).hexdigest() == g["sha256"][name], (k, name)
+        d = ctx.decode_acc(b["acc"])
+        assert all(d[key] == g["diagnostics"][key] for key in ("total_sdf", "total_iters", "max_sdf", "min_sdf")), (k, d)
+    ctx.close()
+
+
 def test_full_size_properties(rm, gpu_ctx):
     """Size-independent properties at 3840x2160: tile split == whole frame; iterations <= 100;
     a pixel with no iterations has no SDF calls; diagnostics equal a host recount."""
@@ -918,6 +956,28 @@ def test_mixed_rotated_primitives_and_make_transform(rm, gpu_ctx, oracle):
     ob = oracle.OracleScene(accel="BVH", prims=desc)
     for k in range(0, 500, 5):
         assert (d[k], c[k]) == ob.distance(pts[k])
+
+
+def test_torus_radii_of_either_sign_keep_the_primitive_filter_exact(rm, oracle):
+    """the bounding sphere of the general-primitive filter used |major + minor| for a torus, which is not a
+    geometric bound when a radius is negative (legal input: torus.ts:14-25 just subtracts them).  Tori with radii of either
+    sign, filtered against unfiltered (the unfiltered loop is the reference's, oracle-checked by the tests above)."""
+    ctx = rm.Context(0)
+    desc = oracle.synthetic_mixed_prims(45, seed=5)
+    triples = [list(t) for t in oracle.OracleScene(accel="None", prims=desc).prims()]
+    k = 0
+    for t in triples:
+        if t[0] == 2:  # torus: (major, minor)
+            t[2] = [(1.0, -0.5), (-1.0, 2.0), (-0.3, -0.2), (0.4, 0.1)][k % 4] + (0.0,)
+            k += 1
+    assert k >= 8
+    for accel in ("None", "BVH"):
+        outs = []
+        for filt in (1, 0):
+            ctx.set_option("filter", filt)
+            outs.append(gpu_render(rm, ctx, None, accel, 220, 130, (0.2, 0.6), prims=[tuple(t) for t in triples]))
+        assert_same(outs[0], outs[1], "tori with radii of either sign, filter on / off, " + accel)
+    ctx.close()
 
 
 # ---- SURVEY 8(f) N4: SDF operators and the Mandelbulb ------------------------------------------

@@ -114,6 +114,7 @@ SIGNATURES = {
     "rm_debug_read_wave_times": (C.c_int, [_VP, _VP]),
     "rm_debug_read_batch_log": (C.c_int, [_VP, _VP]),
     "rm_debug_read_counts": (C.c_int, [_VP, _VP]),
+    "rm_debug_read_lpt_costs": (C.c_int, [_VP, _VP, C.c_int64]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
     "rm_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
 }

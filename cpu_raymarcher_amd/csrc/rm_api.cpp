@@ -98,8 +98,7 @@ struct rm_ctx {
     int64_t opt_v1_lists = 1;  // v1 BVH kernels: per-ray hit-leaf lists instead of one tree walk per interval advance
     int64_t opt_v1_block = 64;  // v1 kernels: threads per workgroup (one wave: wave slots refill one by one)
     int64_t opt_oct_lean = 1;  // octree, sphere scenes, sphere tracer: render_kernel_oct (rm_kernels.hip) instead of render_kernel<1, false, 0>
-    int64_t opt_lpt = 0;  // v2: longest-first item order from the previous frame's costs.  Off since round 3: with the in-round march steps a
-                          // frame's slowest items are no longer slow enough to pay for the sort launch (alone 1.12 ms without, 1.17 ms with)
+    int64_t opt_lpt = 1;  // v2: longest-first item order from the previous frame's item durations (shortens the tail of a frame that runs alone: 1.13 -> 1.08 ms)
     // LPT buffers: a ring of slots, one per launch in flight (a launch sorts from the previous launch's costs into its own
     // permutation and records its own costs); geometry changes restart the feedback
     static constexpr int kLptSlots = 16;
@@ -1265,6 +1264,19 @@ int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608) {
     RM_HIP(ctx, hipDeviceSynchronize());
     RM_HIP(ctx, hipMemcpy(out196608, ctx->d_stamps + 40 + 3 * 8192, 2048 * 96 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     RM_HIP(ctx, hipMemset(ctx->d_stamps + 40 + 3 * 8192, 0, 2048 * 96 * sizeof(uint32_t)));
+    return RM_OK;
+}
+
+// the item costs (durations in units of 2.56 us, one byte per item, 64 queues x kLptStride slots) the LAST v2 launch recorded
+int rm_debug_read_lpt_costs(rm_ctx *ctx, uint8_t *out, int64_t n) {
+    if (!ctx || !out) return RM_E_INVALID;
+    if (!ctx->has_device) return fail(ctx, RM_E_NO_DEVICE, "host-only context");
+    const size_t per_slot = static_cast<size_t>(rm_ctx::kLptQueues) * rm_ctx::kLptStride;
+    if (!ctx->d_lpt_cost || ctx->lpt_launch == 0 || n < 0 || static_cast<size_t>(n) > per_slot) return fail(ctx, RM_E_INVALID, "no costs recorded");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());
+    const unsigned slot = (ctx->lpt_launch + rm_ctx::kLptSlots - 1) % rm_ctx::kLptSlots;
+    RM_HIP(ctx, hipMemcpy(out, ctx->d_lpt_cost + slot * per_slot, static_cast<size_t>(n), hipMemcpyDeviceToHost));
     return RM_OK;
 }
 

@@ -981,7 +981,10 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
     // ---- wave state: the tile being consumed ------------------------------------------------
     int tile_col = -1, tile_row = 0, qpos = item_px;  // tile_col < 0: no item yet; qpos: next pixel of the current tile (item_px = used up)
     bool no_more = false;
-    unsigned int item_iters = 0;  // cost feedback for the next frame's longest-first order: wave-loop iterations spent on the current item
+    // cost feedback for the next frame's longest-first order: when the current item was taken (s_memrealtime, 100 MHz; a
+    // cost byte counts units of 10.24 us: the slowest 64-pixel batches of C3 take 0.9 ms).  Until round 3 the cost was the item's
+    // wave-loop iterations; the in-round march steps take time without taking iterations.
+    unsigned int item_t0 = 0;
 
     // ---- lane state (round 3: 21 registers instead of ~44; registers decide this kernel's occupancy) ----------------
     //  * nothing wave-uniform: the ray origin is rebuilt from freshly loaded parameters where a section needs it
@@ -1067,7 +1070,6 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
     for (;;) {
         RM_T(7)
         RM_CNT(0)
-        item_iters += 1;
         // ---- R: active-ray compaction.  Lanes whose ray is finished store their pixel and take
         // the next pixels of the wave's tile stream, assigned by ballot + prefix count. ----------
         const unsigned long long idle = __ballot((st & ST_PHASE) == PH_DONE);
@@ -1098,8 +1100,9 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                 // Tried in round 3 and dropped: claiming one item AHEAD so that the answer is never waited for -- no gain with
                 // frames in flight (919 against 949 frames/s), none alone, one more register held across the wave loop.)
                 if (C.lpt_cost_out && tile_col >= 0) {  // the item just finished: what it cost, at its slot of the queue it was pulled from (= home)
+                    const unsigned int took = (static_cast<unsigned int>(__builtin_amdgcn_s_memrealtime()) - item_t0) >> 10;  // units of 10.24 us
                     if (lane_r == 0) C.lpt_cost_out[static_cast<size_t>(home) * C.lpt_stride + queue_slot_of(Q, home, tile_col, tile_row)] =
-                        static_cast<uint8_t>(item_iters < 255u ? item_iters : 255u);
+                        static_cast<uint8_t>(took < 255u ? (took ? took : 1u) : 255u);
                 }
 #ifdef RM_STAMPS_CLAIM  // diagnostic: how long does the wave wait for its claim?
                 const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                 if (lane_r == 0) claim = atomicAdd(&Q.counters[home * RM_QSTRIDE], 1u);
                 if (pull_tile(Q, home, tile_col, tile_row, lane_r, claim)) {
                     qpos = 0;
-                    item_iters = 0;
+                    if (C.lpt_cost_out) item_t0 = static_cast<unsigned int>(__builtin_amdgcn_s_memrealtime());
                 } else no_more = true;
 #ifdef RM_STAMPS_CLAIM
                 const unsigned long long tc1 = __builtin_amdgcn_s_memrealtime();

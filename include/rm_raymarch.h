@@ -332,6 +332,9 @@ RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 /* Diagnostic builds only (make EXTRA=-DRM_COUNTS): reads and clears the execution counts of sixteen events of the
  * v2 wave loop (scripts/counts.py) or of the v1 octree kernels (scripts/counts_v1.py) -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
 RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);
+/* The item durations (units of 2.56 us, one byte per work item: 64 queues x 4096 slots) the last v2 launch recorded for the
+ * longest-first order of the next one (option lpt); scripts/lpt_costs.py. */
+RM_API int rm_debug_read_lpt_costs(rm_ctx *ctx, uint8_t *out, int64_t n);
 /* Diagnostic builds only (make EXTRA=-DRM_STAMPS): start and end time (100 MHz ticks) of the first 8192 waves of the last
  * v2 launch -- out[w] start of the wave loop, out[8192 + w] end, out[16384 + w] kernel entry, 0 where no wave ran
  * (scripts/tail_hist.py). */

@@ -509,6 +509,26 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
             served = true;
         }
     }
+    // Points no list serves (outside the root box: a ray that overshoots the grid after passing a sphere still takes one
+    // step per remaining interval, each an evaluation of ALL primitives, scene.ts:173).  When many lanes of the wave hold
+    // such a point -- whole batches do -- every lane feeds all N spheres into the SAME scan as the leaf candidates (twelve
+    // instructions per sphere for one-radius scenes) and joins the one exact evaluation below; a few such lanes are
+    // served one at a time by the whole wave afterwards (all_prims_wave).  Round 3: these rounds were 8 % of C3's VALU
+    // instructions with the separate estimate-and-evaluate loop.
+    if (fallback && !served) RM_CNT(13)
+    {
+        const unsigned long long unserved = __ballot(fallback && !served);
+        if (unserved) {
+            const int n = S.n_prims, m = __popcll(unserved);
+            const bool one_by_one = coop && n > 8 && static_cast<long long>(m) * (28 * ((n + 63) / 64) + 250) < 14ll * n + 200;
+            if (!one_by_one && (!UR || n <= 256)) {
+                if (fallback && !served) {
+                    for (int id = 0; id < n; ++id) scan_sphere<UR>(bs, S.spheres[id], id, q);
+                    served = true;
+                }
+            }
+        }
+    }
     // the one exact evaluation of this call
     bool redo = false;
     if (UR && bs.kbest != 0xFFFFFFFFu) {  // decode the keys: best id, and the runner-up's squared distance (rounded down)
@@ -540,7 +560,6 @@ __device__ double bvh_distance_wave(const RmRenderParams &P, const SceneView &S,
 #ifdef RM_STAMPS
     const unsigned long long t_fb0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (fallback && !served) RM_CNT(13)
     const double all = all_prims_wave(S, fallback && !served, q, lane, coop, filter);
 #ifdef RM_STAMPS
     if (dbg_fallback_cycles) *dbg_fallback_cycles += __builtin_amdgcn_s_memtime() - t_fb0;

@@ -250,13 +250,28 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
     ctx->diag_next = nullptr;
     p.diag_block = nullptr;
     const bool empty = p.local_rows <= 0 || p.width <= 0;
-    if (!empty && ctx->d_diag_blocks && (p.diag_out || (p.variant == 2 && p.algorithm == 0)))
+    const bool v2 = p.variant == 2 && p.algorithm == 0;
+    // The one-ray-per-lane kernels run one-wave workgroups: 129 600 waves per 4K frame, each of which would end with five
+    // device-scope atomics and a wait for four of them.  Measured (round 3, frames in flight): Pyramid of Boxes 1 348 frames/s
+    // with that epilogue against 1 561 with the two reduction launches over the stored counters, C5 493 against 512.  So
+    // when the call stores both counter buffers the diagnostics of a v1 launch come from rm_launch_reduce behind it (still one
+    // call for the host, no host synchronisation); the in-kernel epilogue serves the calls that store no counters.
+    RmDiagDevice *reduce_after = nullptr;
+    if (p.diag_out && !v2 && !empty && p.sdf && p.iters) {
+        reduce_after = p.diag_out;
+        p.diag_out = nullptr;
+    }
+    if (!empty && ctx->d_diag_blocks && (p.diag_out || v2))
         p.diag_block = ctx->d_diag_blocks + (ctx->diag_slot++ % rm_ctx::kDiagBlocks);
     if (p.diag_out && empty) {
         const hipError_t ei = rm_launch_reduce_init(p.diag_out, stream);
         if (ei != hipSuccess) return ei;
     }
-    const hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+    hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+    if (e == hipSuccess && reduce_after) {
+        e = rm_launch_reduce_init(reduce_after, stream);
+        if (e == hipSuccess) e = rm_launch_reduce(p.sdf, p.iters, static_cast<int64_t>(p.local_rows) * p.width, reduce_after, stream);
+    }
     if (oct_slot) {  // this stream now reads the table: whoever rewrites it waits for this launch
         hipEvent_t *ev = nullptr;
         for (auto &u : oct_slot->users)

@@ -8,7 +8,7 @@ Round 3: the rank's diagnostics come from the render launch itself (FUSED=1, def
 launches), and GATHER=1 adds the call the real job makes per frame -- an asynchronous RCCL gather of the packed buffer on
 the frame's stream, through a ONE-rank process group (a one-GPU box cannot host two ranks: the transfer is a local copy,
 but the host-side cost of issuing it and of Work.wait() is the real one) -- to the host-enqueue column.
-usage: python scripts/shard_overhead.py [frames] [S=12] [N=8 ...] [WL=C3|C5] [FUSED=0|1] [GATHER=0|1]"""
+usage: python scripts/shard_overhead.py [frames] [S=12] [N=8 ...] [WL=C3|C5] [FUSED=0|1] [GATHER=0|1] [OPT=key=value ...]"""
 import os
 import sys
 import time
@@ -40,6 +40,10 @@ def main():
     ctx = R.Context(0)
     ctx.set_option("blocks_per_cu", 1)  # what bench.py uses with frames in flight
     ctx.set_option("lpt", 0)            # likewise: overlapping frames hide the tail the longest-first order is for
+    for a in sys.argv[1:]:
+        if a.startswith("OPT="):
+            k, v = a[4:].split("=")
+            ctx.set_option(k, int(v))
     if wl == "C5":
         from cpu_raymarcher_amd.synthetic import synthetic_spheres
         scene = R.Scene("Octree", ctx=ctx)

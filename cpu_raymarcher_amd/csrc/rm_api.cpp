@@ -84,6 +84,7 @@ struct rm_ctx {
                          // <= 512 spheres, where the 48^3 candidate grid keeps the lists short: C3 2.65 -> 2.62 ms)
     int64_t opt_blocks_per_cu = 6;  // persistent workgroups per launch and CU: what the kernel's 80 VGPRs and 26 KB of LDS allow (a frame alone, round 3: 4: 1.42 ms, 6: 1.32, 7: 1.30)
     int64_t opt_lds_fill = 0;
+    int64_t opt_item_wide = 0;  // v2: the 64-pixel batches of an item side by side (1) or one above the other (0)
     int64_t opt_multi_step = 1;  // v2 BVH: in-round march steps (rm_render_v2.hip, section M)
     int64_t opt_lds_kb = 0;         // v2: LDS budget per workgroup the launcher trims the hit lists to (0: as many workgroups per CU as the kernel's registers allow; 32: five per CU, 40: four)
     int64_t opt_refill = 64;
@@ -231,7 +232,7 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
         }
         if (ctx->d_lpt_cost) {
             // the costs are per item of THIS tiling of THIS row set: any change restarts the feedback (costs read as zero)
-            const long long geom = ((static_cast<long long>(p.width) * 65536 + p.local_rows) * 1024 + p.tile_w) * 1024 + p.item_px +
+            const long long geom = ((static_cast<long long>(p.width) * 65536 + p.local_rows) * 1024 + p.tile_w) * 1024 + p.item_px + (p.item_wide ? 512 : 0) +
                                    (p.stripe_rows ? (1ll << 62) + p.part * 131 + p.n_parts : 0) + p.y_start * 7919ll;
             const unsigned slot = ctx->lpt_launch % rm_ctx::kLptSlots, prev = (ctx->lpt_launch + rm_ctx::kLptSlots - 1) % rm_ctx::kLptSlots;
             const bool have_prev = ctx->lpt_launch > 0 && geom == ctx->lpt_geometry;
@@ -621,6 +622,7 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
                      ctx->host.spheres.size() == ctx->host.prims.size()) ? 1 : 0;
     p.lds_budget_kb = static_cast<int32_t>(ctx->opt_lds_kb);
     p.lds_fill = static_cast<int32_t>(ctx->opt_lds_fill);
+    p.item_wide = static_cast<int32_t>(ctx->opt_item_wide);
     p.multi_step = static_cast<int32_t>(ctx->opt_multi_step);
     p.uniform_radius = 0;
     if (ctx->opt_uniform && !ctx->host.general && ctx->host.spheres.size() >= 2 &&
@@ -1356,6 +1358,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_multi_step = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "item_wide")) {
+        ctx->opt_item_wide = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "lds_fill")) {
         ctx->opt_lds_fill = value ? 1 : 0;
         return RM_OK;
@@ -1459,6 +1465,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
+    else if (!std::strcmp(key, "item_wide")) *value = ctx->opt_item_wide;
     else if (!std::strcmp(key, "multi_step")) *value = ctx->opt_multi_step;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;
     else if (!std::strcmp(key, "item_px")) *value = ctx->opt_item_px;

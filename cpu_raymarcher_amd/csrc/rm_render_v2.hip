@@ -1158,8 +1158,8 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                 if (take) {
                     const int n = qpos + rank;  // pixel n of the tile, in 64-pixel sub-tile order
                     const int sub = n >> 6, l = n & 63;
-                    const int px = (tile_col << C.tile_w_log2) + (l & (Q.tile_w - 1));
-                    const int prow = (tile_row << C.tile_h_log2) + sub * (64 >> C.tile_w_log2) + (l >> C.tile_w_log2);
+                    const int px = (tile_col << C.item_w_log2) + sub * C.sub_dx + (l & (Q.tile_w - 1));
+                    const int prow = (tile_row << C.tile_h_log2) + sub * C.sub_dy + (l >> C.tile_w_log2);
                     if (px < C.width && prow < C.local_rows) {
                         in_frame = true;
                         pidx = static_cast<uint32_t>(prow) * static_cast<uint32_t>(C.width) + static_cast<uint32_t>(px);
@@ -1188,8 +1188,8 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
                     cur.ord = sC;
                     bool hc = false;
                     if (whole_batch) {
-                        const int x0 = tile_col << C.tile_w_log2;
-                        const int r0 = (tile_row << C.tile_h_log2) + batch_sub * (64 >> C.tile_w_log2);
+                        const int x0 = (tile_col << C.item_w_log2) + batch_sub * C.sub_dx;
+                        const int r0 = (tile_row << C.tile_h_log2) + batch_sub * C.sub_dy;
                         const Bundle B = make_bundle(C, x0, x0 + Q.tile_w - 1, row_to_y(C, r0),
                                                      row_to_y(C, r0 + (64 >> C.tile_w_log2) - 1));
                         hc = bvh_prologue_cull<REL>(scene_view<ACCEL, LDS, REL>(C, smem), C, B, in_frame, ray, ri, L, cur, lane_now());
@@ -1567,13 +1567,18 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
     if (p.leaf_order) p.bvh_prim_count = 0;  // the leaf lists are the identity (spheres stored in leaf order): nothing reads them, nothing is staged
     if (p.item_px != 64 && p.item_px != 128 && p.item_px != 256) p.item_px = 64;
     if (p.item_px < p.tile_w) p.item_px = p.tile_w;
-    const int tw = p.tile_w, th = p.item_px / tw;
-    const int tiles_x = (p.width + tw - 1) / tw;
+    const int tw = p.tile_w;
+    const bool wide = p.item_wide != 0 && tw < 64 && p.item_px > 64;  // batches side by side: item_px / 64 of them, each tw x 64 / tw
+    const int iw = wide ? tw * (p.item_px / 64) : tw, th = wide ? 64 / tw : p.item_px / tw;
+    const int tiles_x = (p.width + iw - 1) / iw;
     const int tiles_y = (rows + th - 1) / th;
     auto log2i = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     if ((tw & (tw - 1)) != 0 || tiles_x <= 0 || static_cast<long long>(tiles_x) * (tiles_y + 8) >= (1ll << 31)) return hipErrorInvalidValue;
     p.tile_w_log2 = log2i(tw);
     p.tile_h_log2 = log2i(th);
+    p.item_w_log2 = log2i(iw);
+    p.sub_dx = wide ? tw : 0;
+    p.sub_dy = wide ? 0 : 64 / tw;
     p.tiles_x = tiles_x;
     p.tiles_y = tiles_y;
     p.tiles_x_magic = tiles_x == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / static_cast<unsigned long long>(tiles_x)) + 1u;  // 0: k / 1

@@ -172,6 +172,9 @@ struct RmRenderParams {
     // v2 tile geometry precomputed by the launcher so the refill section has no integer division (tile_w and item_px
     // are powers of two; k / tiles_x through a magic multiplier, exact for k * tiles_x < 2^32)
     int32_t tile_w_log2, tile_h_log2, tiles_x, tiles_y;
+    // an item's 64-pixel batches sit side by side (option `item_wide`: item = (tile_w * item_px / 64) x (64 / tile_w) pixels, the
+    // batches of one wave's item complete whole 128-byte lines of every buffer) or one above the other (item = tile_w x item_px / tile_w)
+    int32_t item_wide, item_w_log2, sub_dx, sub_dy;
     uint32_t tiles_x_magic;
     int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = six workgroups per CU, then five, then four)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads

@@ -128,7 +128,7 @@ def test_error_codes_without_a_device(rm):
     ctx.set_option("tile_w", 16)
     assert ctx.get_option("tile_w") == 16
     # the round-2 knobs: defaults, accepted values, rejected values, unknown keys
-    assert (ctx.get_option("oct_lean"), ctx.get_option("v1_block"), ctx.get_option("v1_lists"), ctx.get_option("lpt")) == (1, 64, 1, 0)
+    assert (ctx.get_option("oct_lean"), ctx.get_option("v1_block"), ctx.get_option("v1_lists"), ctx.get_option("lpt")) == (1, 64, 1, 1)
     # the round-3 knobs
     assert (ctx.get_option("multi_step"), ctx.get_option("blocks_per_cu"), ctx.get_option("lds_kb"), ctx.get_option("lds_fill")) == (1, 6, 0, 0)
     ctx.set_option("static", 75)  # accepted, ignored since round 3

@@ -115,6 +115,9 @@ SIGNATURES = {
     "rm_debug_read_batch_log": (C.c_int, [_VP, _VP]),
     "rm_debug_read_counts": (C.c_int, [_VP, _VP]),
     "rm_debug_read_lpt_costs": (C.c_int, [_VP, _VP, C.c_int64]),
+    "rm_rtc_source": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "rm_rtc_compile_check": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_char_p, C.c_int64, C.POINTER(C.c_double)]),
+    "rm_rtc_status": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int64]),
     "rm_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),
     "rm_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
 }

@@ -245,6 +245,32 @@ class Context:
         """The render-kernel instantiation the last render entry launched (rm_last_kernel)."""
         return N.lib().rm_last_kernel(self._h).decode()
 
+    # ---- run-time specialised kernels of expression forests (rm_rtc_*) -------------------
+    def rtc_source(self):
+        """The straight-line HIP source generated for the active scene's expression forest ("" if none)."""
+        need = C.c_int64(0)
+        N.check(self._h, N.lib().rm_rtc_source(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(1, need.value))
+        N.check(self._h, N.lib().rm_rtc_source(self._h, buf, len(buf), None))
+        return buf.value.decode()
+
+    def rtc_compile_check(self, accel=0, other=False):
+        """Compiles the active scene's specialised kernel for gfx950 without loading it (no GPU needed).
+        Returns (compiler log with the resource-usage remarks, seconds)."""
+        buf = C.create_string_buffer(1 << 16)
+        secs = C.c_double(0)
+        rc = N.lib().rm_rtc_compile_check(self._h, int(accel), int(bool(other)), buf, len(buf), C.byref(secs))
+        if rc != 0:
+            raise RuntimeError("rm_rtc_compile_check: %s\n%s" % (N.lib().rm_last_error(self._h).decode(), buf.value.decode()))
+        return buf.value.decode(), secs.value
+
+    def rtc_status(self):
+        """(kernels compiled for the active scene, compiles that failed, most recent compile log)."""
+        done, bad = C.c_int32(0), C.c_int32(0)
+        buf = C.create_string_buffer(1 << 16)
+        N.check(self._h, N.lib().rm_rtc_status(self._h, C.byref(done), C.byref(bad), buf, len(buf)))
+        return done.value, bad.value, buf.value.decode()
+
     def shade(self, shader, width, height, depth, normal, sdf, iters, rgba):
         npx = max(0, int(width)) * max(0, int(height))
         bufs = dict(depth=depth, normal=normal, sdf=sdf, iters=iters, rgba=rgba)

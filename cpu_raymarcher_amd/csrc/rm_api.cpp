@@ -6,10 +6,12 @@
 // twice per tile per frame (scene.ts:24-29 then raymarchWorker.ts:38).
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -17,6 +19,7 @@
 #include "../../include/rm_raymarch.h"
 #include "rm_diag.h"
 #include "rm_kernels.h"
+#include "rm_rtc.h"
 #include "rm_scene_host.h"
 
 namespace {
@@ -131,6 +134,15 @@ struct rm_ctx {
     int64_t opt_n0_batch = 64;  // v2 BVH: see RmRenderParams::n0_batch
     int64_t opt_length = 0;  // vec3.length: 0 Math.hypot (gl-matrix 3.0 - 3.4.3), 1 Math.sqrt(x*x + y*y + z*z)
     const char *last_kernel = "";
+    // Expression forests: the scene's programs compiled into the one-ray-per-lane kernels at run time (rm_rtc.h; option
+    // `specialise`, default on).  One kernel per (acceleration structure, marcher family, vec3.length form) the scene is
+    // rendered with, compiled at its first launch (1.5 - 3 s, synchronous) and kept until the scene is replaced.  A compile
+    // that fails is remembered with its log (rm_rtc_status) and the interpreter of rm_program.h serves the scene.
+    int64_t opt_specialise = 1;
+    std::string rtc_src;
+    std::map<int, rmrtc::Kernel> rtc_kernels;
+    std::map<int, std::string> rtc_failed;
+    std::string rtc_log;  // of the most recent compile
     // small host tables the sharded entry points need on the device (stripe lists, stripe -> source maps): cached by
     // content, each in its own allocation, so a table a launch in flight still reads is never overwritten
     struct DevTable {
@@ -164,8 +176,25 @@ int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
 }
 
 // the kernels exist twice: vec3.length = Math.hypot, and = sqrt(x*x + y*y + z*z) (rm_kernels.h, option `length`)
+// the scene's specialised kernel for (accel, marcher family, length form), compiled on first use; nullptr: the interpreter serves
+const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
+    if (!ctx->opt_specialise || !ctx->host.program || ctx->rtc_src.empty() || !ctx->has_device) return nullptr;
+    const int key = (accel * 2 + (other ? 1 : 0)) * 2 + (ctx->opt_length ? 1 : 0);
+    auto it = ctx->rtc_kernels.find(key);
+    if (it != ctx->rtc_kernels.end()) return &it->second;
+    if (ctx->rtc_failed.count(key)) return nullptr;
+    rmrtc::Kernel k;
+    if (!rmrtc::compile(ctx->rtc_src, accel, other, ctx->opt_length != 0, true, false, k, ctx->rtc_log)) {
+        ctx->rtc_failed[key] = ctx->rtc_log;
+        return nullptr;
+    }
+    return &(ctx->rtc_kernels[key] = k);
+}
+
 hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
+    const rmrtc::Kernel *special = p.general >= 2 ? specialised_kernel(ctx, p.accel, p.algorithm != 0) : nullptr;
+    p.rtc_function = special ? special->render : nullptr;
     rm_ctx::OctFrameSlot *oct_slot = nullptr;
     if (p.accel == 1 && p.oct_lean && !p.general && p.algorithm == 0 && p.oct_lut && p.oct_recs && p.filter) {
         const size_t n = static_cast<size_t>(p.oct_nodes);
@@ -269,6 +298,7 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
         if (ei != hipSuccess) return ei;
     }
     hipError_t e = ctx->opt_length ? rm_launch_render_sqrt(p, stream, &ctx->last_kernel) : rm_launch_render(p, stream, &ctx->last_kernel);
+    if (special && !empty) ctx->last_kernel = special->name.c_str();
     if (e == hipSuccess && reduce_after) {
         e = rm_launch_reduce_init(reduce_after, stream);
         if (e == hipSuccess) e = rm_launch_reduce(p.sdf, p.iters, static_cast<int64_t>(p.local_rows) * p.width, reduce_after, stream);
@@ -302,6 +332,10 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
     } while (0)
 
 void free_device_scene(rm_ctx *ctx) {
+    for (auto &kv : ctx->rtc_kernels) rmrtc::release(kv.second);  // (callers have synchronised the device)
+    ctx->rtc_kernels.clear();
+    ctx->rtc_failed.clear();
+    ctx->last_kernel = "";
     if (!ctx->has_device) return;
     DeviceScene &d = ctx->dev;
     (void)hipFree(d.spheres);
@@ -356,7 +390,11 @@ int upload_vec(rm_ctx *ctx, const std::vector<T> &v, T **out) {
 }
 
 int upload_scene(rm_ctx *ctx) {
-    if (!ctx->has_device) return RM_OK;
+    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges) : std::string();
+    if (!ctx->has_device) {
+        free_device_scene(ctx);
+        return RM_OK;
+    }
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, hipDeviceSynchronize());  // nothing may still read the old tables
     free_device_scene(ctx);
@@ -1166,6 +1204,10 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     p.oct = ctx->dev.oct;
     p.oct_prims = ctx->dev.oct_prims;
     p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
+    if (p.general >= 2) {
+        const rmrtc::Kernel *special = specialised_kernel(ctx, p.accel, false);
+        p.rtc_function = special ? special->distance : nullptr;
+    }
     RM_HIP(ctx, hipMemcpyAsync(base, points_xyz, 12 * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream));
     RM_HIP(ctx, (ctx->opt_length ? rm_launch_distance_sqrt : rm_launch_distance)(
                     p, reinterpret_cast<const float *>(base), n, reinterpret_cast<double *>(base + o_dist),
@@ -1284,6 +1326,43 @@ int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608) {
     return RM_OK;
 }
 
+// ---- run-time specialisation of expression forests (rm_rtc.h) -------------------------------------------------------------
+static int copy_text(const std::string &t, char *out, int64_t cap, int64_t *needed) {
+    if (needed) *needed = static_cast<int64_t>(t.size()) + 1;
+    if (out && cap > 0) {
+        const size_t n = std::min(static_cast<size_t>(cap - 1), t.size());
+        std::memcpy(out, t.data(), n);
+        out[n] = '\0';
+    }
+    return RM_OK;
+}
+
+int rm_rtc_source(rm_ctx *ctx, char *out, int64_t cap, int64_t *needed) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RM_E_NO_SCENE, "no scene");
+    return copy_text(ctx->rtc_src, out, cap, needed);
+}
+
+int rm_rtc_compile_check(rm_ctx *ctx, int32_t accel, int32_t other, char *log, int64_t cap, double *seconds) {
+    if (!ctx) return RM_E_INVALID;
+    if (!ctx->have_scene || ctx->rtc_src.empty()) return fail(ctx, RM_E_NO_SCENE, "the active scene has no specialised source");
+    rmrtc::Kernel k;
+    std::string text;
+    const bool ok = rmrtc::compile(ctx->rtc_src, norm_accel(accel), other != 0, ctx->opt_length != 0, false, true, k, text);
+    if (seconds) *seconds = k.compile_seconds;
+    copy_text(text, log, cap, nullptr);
+    return ok ? RM_OK : fail(ctx, RM_E_INVALID, "hiprtc: the specialised kernel did not compile (see the log)");
+}
+
+int rm_rtc_status(rm_ctx *ctx, int32_t *compiled, int32_t *failed, char *log, int64_t cap) {
+    if (!ctx) return RM_E_INVALID;
+    if (compiled) *compiled = static_cast<int32_t>(ctx->rtc_kernels.size());
+    if (failed) *failed = static_cast<int32_t>(ctx->rtc_failed.size());
+    std::string why;
+    if (!rmrtc::available(&why)) return copy_text(why, log, cap, nullptr);
+    return copy_text(ctx->rtc_log, log, cap, nullptr);
+}
+
 // the item costs (durations in units of 2.56 us, one byte per item, 64 queues x kLptStride slots) the LAST v2 launch recorded
 int rm_debug_read_lpt_costs(rm_ctx *ctx, uint8_t *out, int64_t n) {
     if (!ctx || !out) return RM_E_INVALID;
@@ -1360,6 +1439,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "item_wide")) {
         ctx->opt_item_wide = value ? 1 : 0;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "specialise")) {
+        ctx->opt_specialise = value ? 1 : 0;
         return RM_OK;
     }
     if (!std::strcmp(key, "lds_fill")) {
@@ -1465,6 +1548,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
+    else if (!std::strcmp(key, "specialise")) *value = ctx->opt_specialise;
     else if (!std::strcmp(key, "item_wide")) *value = ctx->opt_item_wide;
     else if (!std::strcmp(key, "multi_step")) *value = ctx->opt_multi_step;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;

@@ -5,7 +5,9 @@
 //
 // Build with -ffp-contract=off: JS arithmetic has one rounding per operation, no FMA.
 #pragma once
+#ifndef __HIPCC_RTC__  // (hiprtc brings its own runtime declarations: the run-time specialiser of rm_rtc.cpp compiles these files too)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rm_types.h"
 

@@ -15,7 +15,9 @@
 // no fence, whose release half would write back every dirty line of the XCD's L2 -- the pixel stores.  The last wave
 // reads the slots with device-scope atomic loads.  min is kept as max(0xFFFFFFFF - sdfEval): all accumulators start at 0.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rm_kernels.h"
 

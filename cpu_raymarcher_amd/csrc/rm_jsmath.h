@@ -20,7 +20,9 @@
 //   is preserved.
 //   ====================================================
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace rmd {
 

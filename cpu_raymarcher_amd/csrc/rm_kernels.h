@@ -1,7 +1,9 @@
 // rm_kernels.h -- launchers of the gfx950 kernels in rm_kernels.hip.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#endif
 
 #include "rm_types.h"
 
@@ -24,6 +26,7 @@ struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
 #define RM_LEN_TAG ""
 #endif
 
+#ifndef __HIPCC_RTC__  // (host side: the launchers)
 // Renders rows [y_start, y_end) (runRaymarcher + optional fused shade).  *kernel_name (optional) receives the
 // instantiation that was launched (static string).
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
@@ -70,3 +73,4 @@ hipError_t rm_launch_jsmath(int fn, const double *a, const double *b, int64_t n,
 // compares the two device forms of Math.hypot on n generated triples; adds mismatches
 hipError_t rm_launch_fastdiv_selftest(uint64_t seed, int64_t n, unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t rm_launch_recip_selftest(int mode, unsigned long long *d_mismatches, hipStream_t stream);
+#endif  // !__HIPCC_RTC__

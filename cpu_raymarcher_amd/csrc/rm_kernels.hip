@@ -17,7 +17,9 @@
 //   Octree.findNode / marchRay / intersectRayBox              acceleration_structures/octree.ts:195-294
 //   ShadingModel.shade (4 models)                             util/shading_models/*.ts
 //   diagnostics                                               main.ts:528-548
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rm_device.h"
 
@@ -41,6 +43,9 @@ __device__ unsigned long long *rm_cnt_g;
 
 #include "rm_bvh_list.h"
 #include "rm_program.h"
+#ifdef RM_RTC  // the run-time specialiser's build of this file (rm_rtc.cpp): one scene's expression forest as straight-line code
+#include "rm_rtc_scene.inc"
+#endif
 #include "rm_kernels.h"
 #include "rm_diag.h"
 
@@ -87,10 +92,17 @@ __device__ __forceinline__ void v1_diag_epilogue(const RmRenderParams &P, bool h
 // GEN is a compile-time property of the kernel instantiation: a run-time `if (P.general)` in
 // front of the sphere loop changed the results of render_kernel<0, true> (lane-grouping
 // dependent wrong normals with hipcc 7.2), so the two representations never share a function body.
-// GEN: 0 RmSphere records, 1 RmPrim records, 2 expression programs (rm_program.h), 3 programs with a Mandelbulb.
+// GEN: 0 RmSphere records, 1 RmPrim records, 2 expression programs (rm_program.h), 3 programs with a Mandelbulb,
+// 4 (RM_RTC builds only) the scene's programs as generated straight-line code.
 template <int GEN>
 __device__ __forceinline__ double list_min(const RmRenderParams &P, const int32_t *ids, int n, const Vec3f &p,
                                            double closest) {
+#ifdef RM_RTC
+    if (GEN == 4) {  // the scene's own code (generated: rm_rtc.cpp); per-lane object ids, no instruction stream
+        for (int k = 0; k < n; ++k) closest = js_min_nan(rm_rtc_object_sdf(ids ? ids[k] : k, p, P.time), closest);
+        return closest;
+    }
+#endif
     if (GEN >= 2) {  // Math.min(primitive.sdf(position), closestDistance), NaN-propagating
         for (int k = 0; k < n; ++k) {
             const int obj = ids ? ids[k] : k;
@@ -663,6 +675,7 @@ __device__ __forceinline__ int v1_tile_of_block(int b) {
     return (b & ~63) + ((r & 7) << 3) + (r >> 3);
 }
 
+#ifndef RM_RTC  // (the lean octree kernel serves sphere scenes only)
 // ------------------------------------------------------------------ the octree sphere tracer, lean form
 //
 // render_kernel<1, false, 0> spends 60 % of its instructions in the part of the march step that precedes the distance
@@ -915,8 +928,10 @@ __global__ __launch_bounds__(64, 8) void render_kernel_oct(const RmRenderParams 
     v1_diag_epilogue(P, in_frame, counters >> 16, counters & 0xFFFFu);
 }
 
+#endif  // !RM_RTC
+
 template <int ACCEL, bool OTHER, int GEN>
-__global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
+__device__ __forceinline__ void render_body(const RmRenderParams &P) {
     // wave tile: tile_w x (64 / tile_w); the waves of a workgroup (blockDim / 64: option `v1_block`) stacked vertically
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = P.tile_w, th = 64 / tw;
@@ -975,6 +990,28 @@ __global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
     if (P.rgba) reinterpret_cast<uchar4 *>(P.rgba)[idx] = shade_pixel(P.shader, db, nb[0], nb[1], nb[2], c16, i16, P.light_d);
     }
     v1_diag_epilogue(P, in_frame, c16, i16);
+}
+
+template <int ACCEL, int GEN>
+__device__ __forceinline__ void distance_body(const RmRenderParams &P, const float *pts, int64_t n, double *dist, uint32_t *count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Vec3f p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    uint32_t c = 0;
+    dist[i] = scene_distance<ACCEL, GEN>(P, p, c);
+    count[i] = c;
+}
+
+#ifdef RM_RTC
+}  // namespace
+extern "C" __global__ __launch_bounds__(256) void rm_rtc_render(const RmRenderParams P) { render_body<RM_RTC_ACCEL, RM_RTC_OTHER != 0, 4>(P); }
+extern "C" __global__ __launch_bounds__(256) void rm_rtc_distance(const RmRenderParams P, const float *pts, int64_t n, double *dist, uint32_t *count) {
+    distance_body<RM_RTC_ACCEL, 4>(P, pts, n, dist, count);
+}
+#else
+template <int ACCEL, bool OTHER, int GEN>
+__global__ __launch_bounds__(256) void render_kernel(const RmRenderParams P) {
+    render_body<ACCEL, OTHER, GEN>(P);
 }
 
 #ifndef RM_LENGTH_SQRT  // scene-independent kernels exist once (this file is compiled a second time with -DRM_LENGTH_SQRT)
@@ -1100,12 +1137,7 @@ __global__ void reduce_init_kernel(RmDiagDevice *acc) {
 template <int ACCEL, int GEN>
 __global__ __launch_bounds__(256) void distance_kernel(const RmRenderParams P, const float *pts, int64_t n, double *dist,
                                                        uint32_t *count) {
-    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-    if (i >= n) return;
-    Vec3f p{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
-    uint32_t c = 0;
-    dist[i] = scene_distance<ACCEL, GEN>(P, p, c);
-    count[i] = c;
+    distance_body<ACCEL, GEN>(P, pts, n, dist, count);
 }
 
 #ifndef RM_LENGTH_SQRT
@@ -1212,13 +1244,19 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
     const int tiles_y = (rows + wpw * th - 1) / (wpw * th);
     const dim3 grid((static_cast<unsigned>(tiles_x) * static_cast<unsigned>(tiles_y) + 63u) & ~63u), block(static_cast<unsigned>(threads));  // v1_tile_of_block
     // expression programs keep their position slots and pending values in LDS (rm_program.h)
-    size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * threads : 0;
+    size_t shmem = p.general >= 2 && !p.rtc_function ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * threads : 0;
     RmRenderParams pl = p;
     pl.v1_list_offset = -1;
     const size_t list_bytes = static_cast<size_t>(2) * RM_V1_LIST_CAP * threads;
     if (p.accel == 2 && p.v1_lists && p.general < 2 && p.bvh_nodes < 65536 && shmem + list_bytes <= 64 * 1024) {
         pl.v1_list_offset = static_cast<int32_t>((shmem + 15) & ~static_cast<size_t>(15));  // per-ray hit-leaf lists behind the program slots
         shmem = static_cast<size_t>(pl.v1_list_offset) + list_bytes;
+    }
+    if (p.general >= 2 && p.rtc_function) {  // this scene's run-time specialised kernel (rm_rtc.h): same grid, no interpreter state in LDS
+        size_t bytes = sizeof pl;
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(const_cast<void *>(p.rtc_function)), grid.x, 1, 1, block.x, 1, 1, 0, stream, nullptr,
+                                     extra);
     }
 #define RM_V1(A, O, G)                                                                       \
     {                                                                                        \
@@ -1290,6 +1328,19 @@ hipError_t RM_LEN_VARIANT(rm_launch_distance)(const RmRenderParams &p, const flo
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
     const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
+    if (p.general >= 2 && p.rtc_function) {  // rm_rtc_distance(RmRenderParams, const float *, int64_t, double *, uint32_t *)
+        struct Args {
+            RmRenderParams p;
+            const float *points;
+            int64_t n;
+            double *dist;
+            uint32_t *count;
+        } args{p, points, n, dist, count};
+        static_assert(sizeof(RmRenderParams) % 8 == 0 && alignof(RmRenderParams) == 8, "kernel argument layout");
+        size_t bytes = sizeof args;
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(const_cast<void *>(p.rtc_function)), grid.x, 1, 1, 256, 1, 1, 0, stream, nullptr, extra);
+    }
 #define RM_DK(A, G) hipLaunchKernelGGL((distance_kernel<A, G>), grid, block, shmem, stream, p, points, n, dist, count)
     if (p.general == 3) { if (p.accel == 2) RM_DK(2, 3); else if (p.accel == 1) RM_DK(1, 3); else RM_DK(0, 3); }
     else if (p.general == 2) { if (p.accel == 2) RM_DK(2, 2); else if (p.accel == 1) RM_DK(1, 2); else RM_DK(0, 2); }
@@ -1329,3 +1380,4 @@ hipError_t rm_launch_hypot(const float *xyz, int64_t n, double *out, hipStream_t
     return hipGetLastError();
 }
 #endif  // !RM_LENGTH_SQRT
+#endif  // !RM_RTC

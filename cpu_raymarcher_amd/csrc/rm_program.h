@@ -140,6 +140,53 @@ __device__ inline double mandelbulb_sdf(PrmPtr prm, float lx, float ly, float lz
     return 0.5 * mb_log(r) * r / dr;
 }
 
+// The arithmetic of every node kind, shared by the interpreter below and by the straight-line code the run-time specialiser
+// generates for a scene (rm_rtc.cpp): one statement of each formula, two ways of sequencing them.
+__device__ __forceinline__ double leaf_box(float lx, float ly, float lz, double hx, double hy, double hz) {  // box.ts:13-30
+    const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - hx);
+    const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - hy);
+    const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - hz);
+    const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
+    const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
+    return vec3_length(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
+}
+__device__ __forceinline__ double leaf_torus(float lx, float ly, float lz, double major, double minor) {  // torus.ts:14-25
+    const double dx = lx, dy = ly, dz = lz;
+    const double qx = __builtin_sqrt(dx * dx + dz * dz) - major;
+    return __builtin_sqrt(qx * qx + dy * dy) - minor;
+}
+__device__ __forceinline__ double leaf_sphere(float lx, float ly, float lz, double r) { return vec3_length(lx, ly, lz) - r; }  // sphere.ts:12-14
+__device__ __forceinline__ double post_smooth_union(double d1, double d2, double k4) {  // smoothUnion.ts:31-34 (k4 = k * 4.0)
+    const double h = js_max_nan(k4 - __builtin_fabs(d1 - d2), 0.0);
+    return js_min_nan(d1, d2) - h * h * 0.25 / k4;
+}
+__device__ __forceinline__ double post_smooth_subtraction(double d1, double d2, double k4) {  // smoothSubstraction.ts:30-33
+    const double h = js_max_nan(k4 - __builtin_fabs(d1 + d2), 0.0);
+    return js_max_nan(d1, -d2) + h * h * 0.25 / k4;
+}
+// animatedTranslate.ts:34-49: local - direction * (sin(time*speed)*amplitude)
+__device__ __forceinline__ void pre_animated_translate(float lx, float ly, float lz, double d0, double d1, double d2, double amplitude, double speed,
+                                                       double time, float &wx, float &wy, float &wz) {
+    const double offset = js_sin(time * speed) * amplitude;
+    wx = to_f32(static_cast<double>(lx) - static_cast<double>(to_f32(d0 * offset)));
+    wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(d1 * offset)));
+    wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(d2 * offset)));
+}
+__device__ __forceinline__ void pre_twist(double k, float &wx, float wy, float &wz) {  // twist.ts:21-33
+    const double a = k * static_cast<double>(wy);
+    double c, s;
+    js_sincos(a, s, c);
+    const float tx = to_f32(c * static_cast<double>(wx) - s * static_cast<double>(wz));
+    const float tz = to_f32(s * static_cast<double>(wx) + c * static_cast<double>(wz));
+    wx = tx;
+    wz = tz;
+}
+__device__ __forceinline__ void pre_repetition(double s0, double s1, double s2, float &wx, float &wy, float &wz) {  // repetition.ts:20-24
+    wx = to_f32(static_cast<double>(wx) - s0 * js_round(static_cast<double>(wx) / s0));
+    wy = to_f32(static_cast<double>(wy) - s1 * js_round(static_cast<double>(wy) / s1));
+    wz = to_f32(static_cast<double>(wz) - s2 * js_round(static_cast<double>(wz) / s2));
+}
+
 // One scene object: returns Primitive.sdf(p) of the root node.  MB = the scene has a Mandelbulb leaf: its fdlibm
 // code doubles the register need (200 against 106 VGPRs), so scenes without one get an instantiation that runs
 // four waves per SIMD instead of two.
@@ -168,13 +215,7 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog_, in
                 const double d1 = val[(sp - 2) * nt], d2 = val[(sp - 1) * nt];
                 const double k = H.p[0] * 4.0;
                 sp -= 1;
-                if (op == 21) {  // smoothUnion.ts:31-34
-                    const double h = js_max_nan(k - __builtin_fabs(d1 - d2), 0.0);
-                    val[(sp - 1) * nt] = js_min_nan(d1, d2) - h * h * 0.25 / k;
-                } else {  // smoothSubstraction.ts:30-33
-                    const double h = js_max_nan(k - __builtin_fabs(d1 + d2), 0.0);
-                    val[(sp - 1) * nt] = js_max_nan(d1, -d2) + h * h * 0.25 / k;
-                }
+                val[(sp - 1) * nt] = op == 21 ? post_smooth_union(d1, d2, k) : post_smooth_subtraction(d1, d2, k);
             }
             continue;
         }
@@ -185,48 +226,22 @@ __device__ __attribute__((noinline)) double program_sdf(const RmInstr *prog_, in
         }
         if (op < 10) {  // leaves
             double d;
-            if (op == 1) {  // box.ts:13-30
-                const float e0 = to_f32(__builtin_fabs(static_cast<double>(lx)) - H.p[0]);
-                const float e1 = to_f32(__builtin_fabs(static_cast<double>(ly)) - H.p[1]);
-                const float e2 = to_f32(__builtin_fabs(static_cast<double>(lz)) - H.p[2]);
-                const float o0 = e0 > 0.f ? e0 : 0.f, o1 = e1 > 0.f ? e1 : 0.f, o2 = e2 > 0.f ? e2 : 0.f;
-                const float big = e0 > (e1 > e2 ? e1 : e2) ? e0 : (e1 > e2 ? e1 : e2);
-                d = vec3_length(o0, o1, o2) + (big < 0.f ? static_cast<double>(big) : 0.0);
-            } else if (op == 2) {  // torus.ts:14-25
-                const double dx = lx, dy = ly, dz = lz;
-                const double qx = __builtin_sqrt(dx * dx + dz * dz) - H.p[0];
-                d = __builtin_sqrt(qx * qx + dy * dy) - H.p[1];
-            } else if (MB && op == 3) {
-                d = mandelbulb_sdf(H.p, lx, ly, lz, time);
-            } else {  // sphere.ts:12-14
-                d = vec3_length(lx, ly, lz) - H.p[0];
-            }
+            if (op == 1) d = leaf_box(lx, ly, lz, H.p[0], H.p[1], H.p[2]);
+            else if (op == 2) d = leaf_torus(lx, ly, lz, H.p[0], H.p[1]);
+            else if (MB && op == 3) d = mandelbulb_sdf(H.p, lx, ly, lz, time);
+            else d = leaf_sphere(lx, ly, lz, H.p[0]);
             val[sp * nt] = d;
             sp += 1;
             continue;
         }
         // PRE: the point the operands see
         float wx, wy, wz;
-        if (op == 15) {  // animatedTranslate.ts:34-49: local - direction * (sin(time*speed)*amplitude)
-            const double offset = js_sin(time * H.p[4]) * H.p[3];
-            wx = to_f32(static_cast<double>(lx) - static_cast<double>(to_f32(H.p[0] * offset)));
-            wy = to_f32(static_cast<double>(ly) - static_cast<double>(to_f32(H.p[1] * offset)));
-            wz = to_f32(static_cast<double>(lz) - static_cast<double>(to_f32(H.p[2] * offset)));
+        if (op == 15) {
+            pre_animated_translate(lx, ly, lz, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], time, wx, wy, wz);
         } else {
             transform_head(I->Tinv, H.ti, ((H.flags >> 1) & 1) | ((H.flags >> 3) & 1) << 2, lx, ly, lz, wx, wy, wz);  // "convert local position back to world space"
-            if (op == 13) {  // twist.ts:21-33
-                const double a = H.p[0] * static_cast<double>(wy);
-                double c, s;
-                js_sincos(a, s, c);
-                const float tx = to_f32(c * static_cast<double>(wx) - s * static_cast<double>(wz));
-                const float tz = to_f32(s * static_cast<double>(wx) + c * static_cast<double>(wz));
-                wx = tx;
-                wz = tz;
-            } else if (op == 14) {  // repetition.ts:20-24
-                wx = to_f32(static_cast<double>(wx) - H.p[0] * js_round(static_cast<double>(wx) / H.p[0]));
-                wy = to_f32(static_cast<double>(wy) - H.p[1] * js_round(static_cast<double>(wy) / H.p[1]));
-                wz = to_f32(static_cast<double>(wz) - H.p[2] * js_round(static_cast<double>(wz) / H.p[2]));
-            }
+            if (op == 13) pre_twist(H.p[0], wx, wy, wz);
+            else if (op == 14) pre_repetition(H.p[0], H.p[1], H.p[2], wx, wy, wz);
         }
         float *dst = pos + H.dst * 3 * nt;
         dst[0] = wx;

@@ -1,0 +1,41 @@
+// rm_rtc.h -- run-time specialisation of the one-ray-per-lane kernels for ONE scene's expression forest.
+//
+// The reference evaluates an SDF operator tree by virtual calls (Primitive.sdf, primitive.ts:33-39, and the overrides in
+// primitive_operations/*.ts).  The interpreter of rm_program.h walks the same tree as an instruction stream: every
+// instruction costs a scalar-cache round trip, a branch tree and LDS traffic whatever it computes.  A GPU's answer to a
+// scene that changes rarely and is evaluated 10^8 times per frame is to compile it: the forest becomes straight-line HIP
+// (the same formula functions of rm_program.h, called in the interpreter's order, every matrix and parameter a literal)
+// and hiprtc builds render_body<ACCEL, OTHER, 4> of rm_kernels.hip around it for gfx950.  The sources compiled at run time
+// are the ones this library was built from (embedded at build time), with the library's own flags (-ffp-contract=off).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "rm_types.h"
+
+namespace rmrtc {
+
+struct Kernel {
+    void *module = nullptr;       // hipModule_t
+    void *render = nullptr;       // hipFunction_t of rm_rtc_render(RmRenderParams)
+    void *distance = nullptr;     // hipFunction_t of rm_rtc_distance(RmRenderParams, const float *, int64_t, double *, uint32_t *)
+    std::string name;             // "rm_rtc_render<ACCEL, OTHER>" + length tag, as rm_last_kernel reports it
+    double compile_seconds = 0;
+};
+
+// Straight-line source of a scene's programs: defines rmd::rm_rtc_object_sdf(int obj, const Vec3f &p, double time).
+// Empty when the forest is too large to be worth a compile (more than kMaxObjects objects or kMaxInstructions instructions).
+constexpr int kMaxObjects = 32, kMaxInstructions = 512;
+std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges);
+
+// hiprtc is loaded on first use (dlopen): false + reason when this machine has none.
+bool available(std::string *why);
+
+// Compiles rm_kernels.hip for (accel, other, length) around scene_src.  With load_module the code object is loaded into the
+// current device's context and the kernel handles are looked up; without (a machine with no GPU: tests of the build) only the
+// compile is done.  *log receives hiprtc's log (resource-usage remarks included when want_remarks).
+bool compile(const std::string &scene_src, int accel, bool other, bool length_sqrt, bool load_module, bool want_remarks, Kernel &out,
+             std::string &log);
+void release(Kernel &k);
+
+}  // namespace rmrtc

@@ -11,7 +11,18 @@
 // Dense Sphere Grid: 125 spheres (2 KB + 1 KB), 127 BVH nodes (4 KB).  10k synthetic:
 // 160 KB + 80 KB spheres, 2441 octree nodes (117 KB) + ~1.2 MB of leaf ids.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else  // hiprtc keeps the fixed-width names in a namespace of its own
+using __hip_internal::int8_t;
+using __hip_internal::int16_t;
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint8_t;
+using __hip_internal::uint16_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 // One BVH node (bvh.ts:6-22), flattened.  Nodes are stored in the order in which
 // BVH.findRayIntersections (bvh.ts:136-173) pops them: it pushes left then right, so the
@@ -175,6 +186,8 @@ struct RmRenderParams {
     // an item's 64-pixel batches sit side by side (option `item_wide`: item = (tile_w * item_px / 64) x (64 / tile_w) pixels, the
     // batches of one wave's item complete whole 128-byte lines of every buffer) or one above the other (item = tile_w x item_px / tile_w)
     int32_t item_wide, item_w_log2, sub_dx, sub_dy;
+    // Host side only (the launchers): the hipFunction_t of this scene's run-time specialised kernel (rm_rtc.h), or null
+    const void *rtc_function;
     uint32_t tiles_x_magic;
     int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = six workgroups per CU, then five, then four)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads

@@ -329,6 +329,20 @@ RM_API int rm_selftest_recip(rm_ctx *ctx, int mode, uint64_t *mismatches);
  * accumulators of the v2 wave loop (all zero in the product build). */
 RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
 
+/* Run-time specialisation of expression forests (option `specialise`, default 1).  The reference evaluates an operator tree
+ * by virtual dispatch (src/util/primitives/primitive.ts:33-39 and the overrides in src/util/primitive_operations/ *.ts); here the
+ * active scene's trees are emitted as straight-line HIP and compiled for gfx950 with hiprtc into the one-ray-per-lane kernels,
+ * once per (acceleration structure, marcher family) the scene is rendered with, at the first such render (1.5 - 3 s,
+ * synchronous).  Without libhiprtc.so, for forests above 32 objects / 512 instructions, or with `specialise` = 0 the device
+ * interpreter serves the scene (same results: both call the same formula functions in the same order).
+ *   rm_rtc_source         the generated source of the active scene (NUL-terminated, truncated to cap; *needed = full size)
+ *   rm_rtc_compile_check  compiles it for (accel, other != 0: the marchers other than the sphere tracer) without loading the
+ *                         result -- works on a host-only context; log receives the compiler's resource-usage remarks
+ *   rm_rtc_status         kernels compiled / failed for the active scene and the most recent compile log (or why hiprtc is absent) */
+RM_API int rm_rtc_source(rm_ctx *ctx, char *out, int64_t cap, int64_t *needed);
+RM_API int rm_rtc_compile_check(rm_ctx *ctx, int32_t accel, int32_t other, char *log, int64_t cap, double *seconds);
+RM_API int rm_rtc_status(rm_ctx *ctx, int32_t *compiled, int32_t *failed, char *log, int64_t cap);
+
 /* Diagnostic builds only (make EXTRA=-DRM_COUNTS): reads and clears the execution counts of sixteen events of the
  * v2 wave loop (scripts/counts.py) or of the v1 octree kernels (scripts/counts_v1.py) -- out32[i] wave-level executions, out32[i + 16] lanes active in them (all zero in the product build). */
 RM_API int rm_debug_read_counts(rm_ctx *ctx, uint64_t *out32);

@@ -24,6 +24,10 @@ WL = {
     "C5b": dict(synthetic=10000, accel="BVH", W=960, H=540, shader="iteration-heatmap"),
     "N3mixed": dict(mixed=40, accel="BVH", W=3840, H=2160, shader="phong"),
     "N4chicken": dict(preset=17, accel="BVH", W=3840, H=2160, shader="phong"),
+    "N4screw": dict(preset=16, accel="BVH", W=3840, H=2160, shader="phong"),
+    "N4mandel": dict(preset=13, accel="BVH", W=1920, H=1080, shader="phong"),
+    "N4sixty7": dict(preset=18, accel="BVH", W=3840, H=2160, shader="phong"),
+    "N4smooth": dict(preset=11, accel="BVH", W=3840, H=2160, shader="phong"),
 }
 
 
@@ -31,6 +35,7 @@ def main():
     names = [a for a in sys.argv[1:] if "=" not in a] or ["C3"]
     kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     S = int(kv.pop("S", 12))
+    want_hash = kv.pop("hash", None)
     fused = int(kv.pop("fused", 1))  # diagnostics from the render kernel itself (rm_render_attach_diagnostics); 0: reduce kernels
     frames = int(kv.pop("frames", 96))
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
@@ -66,6 +71,8 @@ def main():
         render(b)
         torch.cuda.synchronize()
         verdict = "(no fixture)"
+        if want_hash:
+            verdict = hashlib.sha256(b"".join(t.cpu().numpy().tobytes() for t in (b["d"], b["n"], b["s"], b["i"], b["r"]))).hexdigest()[:16]
         if "golden" in wl:
             g = golden[wl["golden"]]["sha256"]
             bad = [k for k, t in (("depth", b["d"]), ("normal", b["n"]), ("sdf", b["s"]), ("iters", b["i"]), ("rgba", b["r"]))

@@ -139,6 +139,7 @@ struct rm_ctx {
     // rendered with, compiled at its first launch (1.5 - 3 s, synchronous) and kept until the scene is replaced.  A compile
     // that fails is remembered with its log (rm_rtc_status) and the interpreter of rm_program.h serves the scene.
     int64_t opt_specialise = 1;
+    int64_t opt_prune = 1;  // specialised kernels: exact pruning of smooth unions / subtractions (rm_rtc.cpp); takes effect at the next scene build
     std::string rtc_src;
     std::map<int, rmrtc::Kernel> rtc_kernels;
     std::map<int, std::string> rtc_failed;
@@ -390,7 +391,8 @@ int upload_vec(rm_ctx *ctx, const std::vector<T> &v, T **out) {
 }
 
 int upload_scene(rm_ctx *ctx) {
-    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges) : std::string();
+    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges, ctx->host.prog_tree, ctx->host.prog_roots, ctx->opt_prune != 0)
+                                     : std::string();
     if (!ctx->has_device) {
         free_device_scene(ctx);
         return RM_OK;
@@ -1441,6 +1443,10 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_item_wide = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "prune")) {
+        ctx->opt_prune = value ? 1 : 0;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "specialise")) {
         ctx->opt_specialise = value ? 1 : 0;
         return RM_OK;
@@ -1549,6 +1555,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
     else if (!std::strcmp(key, "specialise")) *value = ctx->opt_specialise;
+    else if (!std::strcmp(key, "prune")) *value = ctx->opt_prune;
     else if (!std::strcmp(key, "item_wide")) *value = ctx->opt_item_wide;
     else if (!std::strcmp(key, "multi_step")) *value = ctx->opt_multi_step;
     else if (!std::strcmp(key, "hw_xcd")) *value = ctx->opt_hw_xcd;

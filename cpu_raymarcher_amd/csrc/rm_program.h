@@ -103,11 +103,18 @@ __device__ __forceinline__ void transform_head(MatPtr m, const float *tcol, int 
 
 // Out-of-line copies for the Mandelbulb's escape loop: inlined, the five fdlibm bodies push the kernel to 226
 // VGPRs (2 waves/SIMD); as calls the register need is the largest callee's, not their sum.
-__device__ __attribute__((noinline)) double mb_atan2(double y, double x) { return js_atan2(y, x); }
-__device__ __attribute__((noinline)) double mb_asin(double x) { return js_asin(x); }
+// (Two independent evaluations share a call: the fdlibm bodies are long dependent chains, and at three waves per SIMD the
+// second chain fills the issue slots the first one leaves empty.)
+__device__ __attribute__((noinline)) void mb_angles(double y, double x, double s, double &theta, double &phi) {
+    theta = js_atan2(y, x);
+    phi = js_asin(s);
+}
 __device__ __attribute__((noinline)) double mb_log(double x) { return js_log(x); }
 __device__ __attribute__((noinline)) void mb_pow_pair(double x, double ya, double yb, double &ra, double &rb) { js_pow_pair(x, ya, yb, ra, rb); }
-__device__ __attribute__((noinline)) void mb_sincos(double x, double &s, double &c) { js_sincos(x, s, c); }
+__device__ __attribute__((noinline)) void mb_sincos2(double a, double b, double &sa, double &ca, double &sb, double &cb) {
+    js_sincos(a, sa, ca);
+    js_sincos(b, sb, cb);
+}
 
 // mandelbulb.ts:37-78; z is a Float32Array: each component store rounds to binary32
 template <typename PrmPtr>
@@ -121,8 +128,8 @@ __device__ inline double mandelbulb_sdf(PrmPtr prm, float lx, float ly, float lz
     for (int i = 0; i < iterations; ++i) {
         r = vec3_length(z0, z1, z2);
         if (r > 2.0) break;
-        double theta = mb_atan2(z1, z0);
-        double phi = mb_asin(static_cast<double>(z2) / r);
+        double theta, phi;
+        mb_angles(z1, z0, static_cast<double>(z2) / r, theta, phi);
         if (animate) phi += time * speed;
         double pw_m1, pw;  // Math.pow(r, power - 1), Math.pow(r, power): one log2(r) for both
         mb_pow_pair(r, power - 1.0, power, pw_m1, pw);
@@ -131,8 +138,7 @@ __device__ inline double mandelbulb_sdf(PrmPtr prm, float lx, float ly, float lz
         theta = theta * power;
         phi = phi * power;
         double sth, cth, sph, cph;  // one argument reduction per angle
-        mb_sincos(theta, sth, cth);
-        mb_sincos(phi, sph, cph);
+        mb_sincos2(theta, phi, sth, cth, sph, cph);
         z0 = to_f32(r * cth * cph + static_cast<double>(p0));
         z1 = to_f32(r * sth * cph + static_cast<double>(p1));
         z2 = to_f32(r * sph + static_cast<double>(p2));

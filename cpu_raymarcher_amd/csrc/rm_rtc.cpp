@@ -5,7 +5,9 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -47,70 +49,302 @@ std::string mat(const char *name, const float *m) {
 }
 std::string slot(int s, char c) { return "s" + std::to_string(s) + c; }
 
-// One object: the interpreter's loop (rm_program.h, program_sdf) unrolled over this object's instructions -- same
-// formula functions, same order, slot numbers and stack depths resolved here.
-bool emit_object(const RmInstr *ins, int count, int index, std::string &out) {
-    int max_slot = 0, max_val = 0, sp = 0;
-    std::string body;
-    for (int pc = 0; pc < count; ++pc) {
-        const RmInstr &I = ins[pc];
-        const int op = I.op;
-        body += "    {  // " + std::to_string(pc) + ": op " + std::to_string(op) + "\n";
-        if (op >= 20) {
-            if (op == 20) {
-                if (sp < 1) return false;
-                body += "        v" + std::to_string(sp - 1) + " = v" + std::to_string(sp - 1) + " - " + lit_d(I.p[0]) + ";\n";
-            } else {
-                if (sp < 2) return false;
-                const std::string d1 = "v" + std::to_string(sp - 2), d2 = "v" + std::to_string(sp - 1);
-                body += "        " + d1 + " = " + (op == 21 ? "post_smooth_union(" : "post_smooth_subtraction(") + d1 + ", " + d2 + ", " + lit_d(I.p[0]) +
-                        " * 4.0);\n";
-                sp -= 1;
+// One object.  Every node of the tree gets a value variable v<n>; operators that move the point (a PRE half in the instruction
+// stream) a point of their own q<n>{x,y,z}.  The arithmetic of a value is the interpreter's (rm_program.h, program_sdf): the
+// same formula functions on the same operands; only the order in which independent subtrees are visited is this file's.
+//
+// Exact pruning of smooth unions / subtractions.  smoothUnion(d1, d2) = min(d1, d2) - h^2 / (4k) with h = max(k - |d1 - d2|, 0)
+// (smoothUnion.ts:31-34; k4 = 4 * smoothness below) IS d1 once d2 - d1 >= k4: h is exactly +0, the quotient +0, and
+// x - (+0) = x.  Likewise smoothSubtraction = max(d1, -d2) + h^2 / (4k), h = max(k4 - |d1 + d2|, 0), is d1 + 0.0 once
+// d1 + d2 >= k4 and -d2 + 0.0 once d1 + d2 <= -k4.  Inside a subtree of spheres, boxes and tori under affine transforms,
+// Round, SmoothUnion and SmoothSubtraction ("bounded"), every node gets a binary32 interval [lo, hi] that contains its
+// value -- leaves from their own formula evaluated in binary32 (twenty instructions against a hundred and fifty binary64
+// ones) with an error margin, operators from their operands' -- and an operand whose interval proves it cannot matter is
+// not evaluated at all.  The Chicken (nine unions of ten boxes, k = 1e-4) evaluates one or two boxes per call instead of ten.
+struct Gen {
+    const RmInstr *prog;
+    const rmh::ProgTreeNode *tree;
+    int n_tree;
+    std::string code;
+    std::vector<int> value_nodes;
+    bool ok = true, prune = true;
+
+    static bool affine(const float *m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; }
+    static bool rigid(const float *m) {
+        if (!affine(m)) return false;
+        for (int a = 0; a < 3; ++a)
+            for (int b = a; b < 3; ++b) {
+                const double dot = double(m[4 * a]) * m[4 * b] + double(m[4 * a + 1]) * m[4 * b + 1] + double(m[4 * a + 2]) * m[4 * b + 2];
+                if (!(std::fabs(dot - (a == b ? 1.0 : 0.0)) <= 1e-6)) return false;
             }
-            body += "    }\n";
-            continue;
-        }
-        if (I.src < 0 || I.src >= RM_PROG_MAX_SLOTS || I.dst < 0 || I.dst >= RM_PROG_MAX_SLOTS) return false;
-        max_slot = std::max(max_slot, I.src);
-        const int fT = (I.flags & 1) | (((I.flags >> 2) & 1) << 2), fI = ((I.flags >> 1) & 1) | (((I.flags >> 3) & 1) << 2);
-        body += "        " + mat("T", I.T) + "\n        float lx, ly, lz;\n";
-        body += "        transform_mat4(T, " + std::to_string(fT) + ", " + slot(I.src, 'x') + ", " + slot(I.src, 'y') + ", " + slot(I.src, 'z') +
-                ", lx, ly, lz);\n";  // primitive.ts:34-35
-        if (op < 10) {
-            const std::string v = "v" + std::to_string(sp);
-            if (op == 1) body += "        " + v + " = leaf_box(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ");\n";
-            else if (op == 2) body += "        " + v + " = leaf_torus(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ");\n";
-            else if (op == 3) {
-                body += "        const double prm[6] = {";
-                for (int k = 0; k < 6; ++k) body += lit_d(I.p[k]) + (k < 5 ? ", " : "");
-                body += "};\n        " + v + " = mandelbulb_sdf(prm, lx, ly, lz, time);\n";
-            } else if (op == 0) body += "        " + v + " = leaf_sphere(lx, ly, lz, " + lit_d(I.p[0]) + ");\n";
-            else return false;
-            sp += 1;
-            max_val = std::max(max_val, sp);
-            if (sp > RM_PROG_MAX_VALS) return false;
-            body += "    }\n";
-            continue;
-        }
-        max_slot = std::max(max_slot, I.dst);
-        body += "        float wx, wy, wz;\n";
-        if (op == 15) {
-            body += "        pre_animated_translate(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ", " + lit_d(I.p[3]) + ", " +
-                    lit_d(I.p[4]) + ", time, wx, wy, wz);\n";
-        } else {
-            body += "        " + mat("Ti", I.Tinv) + "\n";
-            body += "        transform_mat4(Ti, " + std::to_string(fI) + ", lx, ly, lz, wx, wy, wz);\n";
-            if (op == 13) body += "        pre_twist(" + lit_d(I.p[0]) + ", wx, wy, wz);\n";
-            else if (op == 14) body += "        pre_repetition(" + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ", wx, wy, wz);\n";
-            else if (op != 10 && op != 11 && op != 12) return false;
-        }
-        body += "        " + slot(I.dst, 'x') + " = wx;\n        " + slot(I.dst, 'y') + " = wy;\n        " + slot(I.dst, 'z') + " = wz;\n    }\n";
+        for (int k = 0; k < 16; ++k)
+            if (!std::isfinite(m[k])) return false;
+        return true;
     }
-    if (sp < 1) return false;
-    out += "__device__ __forceinline__ double rm_rtc_obj_" + std::to_string(index) + "(float s0x, float s0y, float s0z, double time) {\n";
-    for (int s = 1; s <= max_slot; ++s) out += "    float " + slot(s, 'x') + " = 0.f, " + slot(s, 'y') + " = 0.f, " + slot(s, 'z') + " = 0.f;\n";
-    for (int v = 0; v < std::max(max_val, 1); ++v) out += "    double v" + std::to_string(v) + " = 0.0;\n";
-    out += body + "    return v0;\n}\n";
+    const RmInstr &main_of(int n) const { return prog[tree[n].main]; }
+    int kind(int n) const {  // 0 leaf, 1 round, 2 smooth union, 3 smooth subtraction, 4 point operator without a POST half
+        if (tree[n].main < 0) return 4;
+        const int op = main_of(n).op;
+        return op < 10 ? 0 : (op == 20 ? 1 : (op == 21 ? 2 : 3));
+    }
+    bool bounded(int n) const {
+        const rmh::ProgTreeNode &t = tree[n];
+        switch (kind(n)) {
+            case 0: {
+                const RmInstr &I = main_of(n);
+                if (I.op > 2 || !affine(I.T)) return false;
+                for (int k = 0; k < 16; ++k)
+                    if (!std::isfinite(I.T[k]) || std::fabs(I.T[k]) > 1e6f) return false;
+                for (int k = 0; k < 3; ++k)
+                    if (!std::isfinite(I.p[k]) || std::fabs(I.p[k]) > 1e6) return false;
+                return true;
+            }
+            case 1: return std::isfinite(main_of(n).p[0]) && (t.pre < 0 || (affine(prog[t.pre].T) && affine(prog[t.pre].Tinv))) && bounded(t.a);
+            case 2:
+            case 3: {
+                const double k4 = main_of(n).p[0] * 4.0;
+                return t.pre < 0 && k4 > 0.0 && std::isfinite(k4) && bounded(t.a) && bounded(t.b);
+            }
+            default: return false;
+        }
+    }
+    // Worth the interval pass: three or more leaves, or a blend narrow enough (k4 <= 0.01) that one operand nearly always
+    // decides alone.  (Two leaves under a wide blend -- the "Smooth Union" presets, k4 = 0.8 -- lost 1.5 % to the estimates.)
+    int leaves(int n) const { return kind(n) == 0 ? 1 : leaves(tree[n].a) + (tree[n].b >= 0 ? leaves(tree[n].b) : 0); }
+    double narrowest(int n) const {
+        if (kind(n) == 0) return INFINITY;
+        double w = std::min(narrowest(tree[n].a), tree[n].b >= 0 ? narrowest(tree[n].b) : static_cast<double>(INFINITY));
+        if (kind(n) == 2 || kind(n) == 3) w = std::min(w, main_of(n).p[0] * 4.0);
+        return w;
+    }
+    bool worth_pruning(int n) const { return has_binary(n) && (leaves(n) >= 3 || narrowest(n) <= 0.01); }
+    bool has_binary(int n) const {
+        const int k = kind(n);
+        if (k == 0) return false;
+        if (k == 2 || k == 3) return true;
+        return has_binary(tree[n].a);
+    }
+    static std::string P(const std::string &base, char c) { return base + c; }
+    std::string v(int n) const { return "v" + std::to_string(n); }
+    void line(int ind, const std::string &t) { code += std::string(static_cast<size_t>(4 * ind), ' ') + t + "\n"; }
+
+    // local = transformMat4(point, T) of instruction I into lx, ly, lz (primitive.ts:34-35)
+    void emit_local(int ind, const RmInstr &I, const std::string &pt) {
+        const int fT = (I.flags & 1) | (((I.flags >> 2) & 1) << 2);
+        line(ind, mat("T", I.T));
+        line(ind, "float lx, ly, lz;");
+        line(ind, "transform_mat4(T, " + std::to_string(fT) + ", " + P(pt, 'x') + ", " + P(pt, 'y') + ", " + P(pt, 'z') + ", lx, ly, lz);");
+    }
+    // `pinned`: the leaf sits under an `if` of the pruning code.  Its arithmetic is pure, and the optimiser hoisted the first
+    // sixty instructions of every guarded leaf above its guard (measured: more VALU instructions than without pruning); a
+    // volatile (empty) asm statement on the point cannot be speculated, and everything computed from it stays below the branch.
+    void emit_leaf(int ind, int n, const std::string &pt_in, bool pinned = false) {
+        const RmInstr &I = main_of(n);
+        line(ind, "{  // node " + std::to_string(n) + ": leaf " + std::to_string(I.op));
+        std::string pt = pt_in;
+        if (pinned) {
+            line(ind + 1, "float gx = " + P(pt_in, 'x') + ", gy = " + P(pt_in, 'y') + ", gz = " + P(pt_in, 'z') + ";");
+            line(ind + 1, "asm volatile(\"\" : \"+v\"(gx), \"+v\"(gy), \"+v\"(gz));");
+            pt = "g";
+        }
+        emit_local(ind + 1, I, pt);
+        if (I.op == 1) line(ind + 1, v(n) + " = leaf_box(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ");");
+        else if (I.op == 2) line(ind + 1, v(n) + " = leaf_torus(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ");");
+        else if (I.op == 3) {
+            std::string prm = "const double prm[6] = {";
+            for (int k = 0; k < 6; ++k) prm += lit_d(I.p[k]) + (k < 5 ? ", " : "");
+            line(ind + 1, prm + "};");
+            line(ind + 1, v(n) + " = mandelbulb_sdf(prm, lx, ly, lz, time);");
+        } else if (I.op == 0) line(ind + 1, v(n) + " = leaf_sphere(lx, ly, lz, " + lit_d(I.p[0]) + ");");
+        else ok = false;
+        line(ind, "}");
+    }
+    // the PRE half of node n: the point its operands see, into q<n>{x,y,z} (declared by the caller)
+    void emit_pre(int ind, int n, const std::string &pt) {
+        const RmInstr &I = prog[tree[n].pre];
+        const std::string q = "q" + std::to_string(n);
+        line(ind, "{  // node " + std::to_string(n) + ": operator " + std::to_string(I.op) + ", the point its operands see");
+        emit_local(ind + 1, I, pt);
+        line(ind + 1, "float wx, wy, wz;");
+        if (I.op == 15) {
+            line(ind + 1, "pre_animated_translate(lx, ly, lz, " + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ", " + lit_d(I.p[3]) + ", " +
+                              lit_d(I.p[4]) + ", time, wx, wy, wz);");
+        } else {
+            const int fI = ((I.flags >> 1) & 1) | (((I.flags >> 3) & 1) << 2);
+            line(ind + 1, mat("Ti", I.Tinv));
+            line(ind + 1, "transform_mat4(Ti, " + std::to_string(fI) + ", lx, ly, lz, wx, wy, wz);");  // "convert local position back to world space"
+            if (I.op == 13) line(ind + 1, "pre_twist(" + lit_d(I.p[0]) + ", wx, wy, wz);");
+            else if (I.op == 14) line(ind + 1, "pre_repetition(" + lit_d(I.p[0]) + ", " + lit_d(I.p[1]) + ", " + lit_d(I.p[2]) + ", wx, wy, wz);");
+            else if (I.op < 10 || I.op > 12) ok = false;
+        }
+        line(ind + 1, P(q, 'x') + " = wx;");
+        line(ind + 1, P(q, 'y') + " = wy;");
+        line(ind + 1, P(q, 'z') + " = wz;");
+        line(ind, "}");
+    }
+    std::string post_expr(int n) const {
+        const rmh::ProgTreeNode &t = tree[n];
+        const RmInstr &I = main_of(n);
+        if (I.op == 20) return v(t.a) + " - " + lit_d(I.p[0]);  // round.ts:24
+        return std::string(I.op == 21 ? "post_smooth_union(" : "post_smooth_subtraction(") + v(t.a) + ", " + v(t.b) + ", " + lit_d(I.p[0]) + " * 4.0)";
+    }
+
+    // ---- any node, no pruning ----
+    void emit_node(int ind, int n, const std::string &pt) {
+        if (!ok || n < 0 || n >= n_tree) {
+            ok = false;
+            return;
+        }
+        value_nodes.push_back(n);
+        const rmh::ProgTreeNode &t = tree[n];
+        if (prune && kind(n) != 0 && bounded(n) && worth_pruning(n)) return emit_bounded(ind, n, pt);
+        if (kind(n) == 0) return emit_leaf(ind, n, pt);
+        std::string child_pt = pt;
+        if (t.pre >= 0) {
+            child_pt = "q" + std::to_string(n);
+            line(ind, "float " + P(child_pt, 'x') + ", " + P(child_pt, 'y') + ", " + P(child_pt, 'z') + ";");
+            emit_pre(ind, n, pt);
+        }
+        emit_node(ind, t.a, child_pt);
+        if (kind(n) == 2 || kind(n) == 3) emit_node(ind, t.b, child_pt);
+        if (kind(n) == 4) line(ind, v(n) + " = " + v(t.a) + ";");
+        else line(ind, v(n) + " = " + post_expr(n) + ";");
+    }
+
+    // ---- a bounded subtree: points, intervals, then only the operands that can matter ----
+    void bounded_points(int ind, int n, const std::string &pt, std::vector<std::string> &point_of) {
+        const rmh::ProgTreeNode &t = tree[n];
+        point_of[static_cast<size_t>(n)] = pt;
+        if (kind(n) == 0) return;
+        std::string child_pt = pt;
+        if (t.pre >= 0) {
+            child_pt = "q" + std::to_string(n);
+            line(ind, "float " + P(child_pt, 'x') + ", " + P(child_pt, 'y') + ", " + P(child_pt, 'z') + ";");
+            emit_pre(ind, n, pt);
+        }
+        bounded_points(ind, t.a, child_pt, point_of);
+        if (t.b >= 0) bounded_points(ind, t.b, child_pt, point_of);
+    }
+    void bounded_intervals(int ind, int n, const std::vector<std::string> &point_of) {
+        const rmh::ProgTreeNode &t = tree[n];
+        const std::string lo = "lo" + std::to_string(n), hi = "hi" + std::to_string(n);
+        if (kind(n) == 0) {
+            // the leaf's own formula in binary32 on binary32 local coordinates, +- a margin that covers both roundings: the
+            // formulas are 1-Lipschitz in the local point, whose binary32 form is within 4 ulp of the magnitudes summed
+            // (|m_ij| |p_j|, |t_i|) of the exact path's; the margin is ~40 times that.
+            const RmInstr &I = main_of(n);
+            const std::string &pt = point_of[static_cast<size_t>(n)];
+            double mmax = 1.0, tsum = 0.0, psum = 0.0;
+            for (int k = 0; k < 12; ++k) mmax = std::max(mmax, std::fabs(double(I.T[k])));
+            for (int k = 12; k < 15; ++k) tsum += std::fabs(double(I.T[k]));
+            for (int k = 0; k < 3; ++k) psum += std::fabs(I.p[k]);
+            const float A = std::nextafter(static_cast<float>(1e-5 * 3.0 * mmax), INFINITY), B = std::nextafter(static_cast<float>(1e-5 * (tsum + psum + 1.0)), INFINITY);
+            line(ind, "float " + lo + ", " + hi + ";");
+            line(ind, "{  // node " + std::to_string(n) + ": binary32 estimate of leaf " + std::to_string(I.op));
+            const std::string x = P(pt, 'x'), y = P(pt, 'y'), z = P(pt, 'z');
+            if (I.flags & 4) {
+                line(ind + 1, "const float ex = " + x + " + " + lit_f(I.T[12]) + ", ey = " + y + " + " + lit_f(I.T[13]) + ", ez = " + z + " + " + lit_f(I.T[14]) + ";");
+            } else {
+                for (int r = 0; r < 3; ++r)
+                    line(ind + 1, std::string("const float e") + "xyz"[r] + " = " + lit_f(I.T[r]) + " * " + x + " + " + lit_f(I.T[4 + r]) + " * " + y + " + " + lit_f(I.T[8 + r]) +
+                                      " * " + z + " + " + lit_f(I.T[12 + r]) + ";");
+            }
+            if (I.op == 0) {
+                line(ind + 1, "const float est = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) - " + lit_f(static_cast<float>(I.p[0])) + ";");
+            } else if (I.op == 1) {
+                line(ind + 1, "const float b0 = __builtin_fabsf(ex) - " + lit_f(static_cast<float>(I.p[0])) + ", b1 = __builtin_fabsf(ey) - " + lit_f(static_cast<float>(I.p[1])) +
+                                  ", b2 = __builtin_fabsf(ez) - " + lit_f(static_cast<float>(I.p[2])) + ";");
+                line(ind + 1, "const float o0 = __builtin_fmaxf(b0, 0.f), o1 = __builtin_fmaxf(b1, 0.f), o2 = __builtin_fmaxf(b2, 0.f);");
+                line(ind + 1, "const float est = __builtin_amdgcn_sqrtf(o0 * o0 + o1 * o1 + o2 * o2) + __builtin_fminf(__builtin_fmaxf(b0, __builtin_fmaxf(b1, b2)), 0.f);");
+            } else {
+                line(ind + 1, "const float qx = __builtin_amdgcn_sqrtf(ex * ex + ez * ez) - " + lit_f(static_cast<float>(I.p[0])) + ";");
+                line(ind + 1, "const float est = __builtin_amdgcn_sqrtf(qx * qx + ey * ey) - " + lit_f(static_cast<float>(I.p[1])) + ";");
+            }
+            line(ind + 1, "const float err = (__builtin_fabsf(" + x + ") + __builtin_fabsf(" + y + ") + __builtin_fabsf(" + z + ")) * " + lit_f(A) + " + " + lit_f(B) + ";");
+            line(ind + 1, lo + " = est - err;");
+            line(ind + 1, hi + " = est + err;");
+            line(ind, "}");
+            return;
+        }
+        bounded_intervals(ind, t.a, point_of);
+        if (t.b >= 0) bounded_intervals(ind, t.b, point_of);
+        const std::string la = "lo" + std::to_string(t.a), ha = "hi" + std::to_string(t.a);
+        const RmInstr &I = main_of(n);
+        if (kind(n) == 1) {
+            const float r = static_cast<float>(I.p[0]);
+            const float ra = std::nextafter(static_cast<float>(std::fabs(I.p[0]) + 1.0), INFINITY);
+            line(ind, "const float " + lo + " = (" + la + " - " + lit_f(r) + ") - (__builtin_fabsf(" + la + ") + " + lit_f(ra) + ") * 1e-6f;");
+            line(ind, "const float " + hi + " = (" + ha + " - " + lit_f(r) + ") + (__builtin_fabsf(" + ha + ") + " + lit_f(ra) + ") * 1e-6f;");
+            return;
+        }
+        const std::string lb = "lo" + std::to_string(t.b), hb = "hi" + std::to_string(t.b);
+        const double k4 = I.p[0] * 4.0;
+        const float q = std::nextafter(static_cast<float>(k4 * 0.25 * (1.0 + 1e-5) + 1e-7), INFINITY);  // h^2 / (4 k) <= k4 / 4
+        if (kind(n) == 2) {
+            line(ind, "const float " + lo + " = __builtin_fminf(" + la + ", " + lb + ") - " + lit_f(q) + ", " + hi + " = __builtin_fminf(" + ha + ", " + hb + ");");
+        } else {
+            line(ind, "const float " + lo + " = __builtin_fmaxf(" + la + ", -" + hb + "), " + hi + " = __builtin_fmaxf(" + ha + ", -" + lb + ") + " + lit_f(q) + ";");
+        }
+    }
+    void bounded_eval(int ind, int n, const std::vector<std::string> &point_of) {
+        const rmh::ProgTreeNode &t = tree[n];
+        value_nodes.push_back(n);
+        if (kind(n) == 0) {
+            return emit_leaf(ind, n, point_of[static_cast<size_t>(n)], true);
+        }
+        if (kind(n) == 1) {
+            bounded_eval(ind, t.a, point_of);
+            line(ind, v(n) + " = " + post_expr(n) + ";");
+            return;
+        }
+        const RmInstr &I = main_of(n);
+        const double k4 = I.p[0] * 4.0;
+        const float K = std::nextafter(static_cast<float>(k4 * (1.0 + 1e-5) + 1e-6), INFINITY);
+        const std::string id = std::to_string(n), la = "lo" + std::to_string(t.a), ha = "hi" + std::to_string(t.a), lb = "lo" + std::to_string(t.b),
+                          hb = "hi" + std::to_string(t.b);
+        // (the margin of the binary32 comparison itself: 1e-6 of the magnitudes compared)
+        if (kind(n) == 2) {
+            line(ind, "const bool na" + id + " = !(" + la + " - " + hb + " > " + lit_f(K) + " + 1e-6f * (__builtin_fabsf(" + la + ") + __builtin_fabsf(" + hb + ")));");
+            line(ind, "const bool nb" + id + " = !(" + lb + " - " + ha + " > " + lit_f(K) + " + 1e-6f * (__builtin_fabsf(" + lb + ") + __builtin_fabsf(" + ha + ")));");
+        } else {
+            line(ind, "const bool na" + id + " = !(" + ha + " + " + hb + " < -(" + lit_f(K) + " + 1e-6f * (__builtin_fabsf(" + ha + ") + __builtin_fabsf(" + hb + "))));");
+            line(ind, "const bool nb" + id + " = !(" + la + " + " + lb + " > " + lit_f(K) + " + 1e-6f * (__builtin_fabsf(" + la + ") + __builtin_fabsf(" + lb + ")));");
+        }
+        line(ind, "if (na" + id + ") {");
+        bounded_eval(ind + 1, t.a, point_of);
+        line(ind, "}");
+        line(ind, "if (nb" + id + ") {");
+        bounded_eval(ind + 1, t.b, point_of);
+        line(ind, "}");
+        line(ind, "if (na" + id + " && nb" + id + ") {");
+        line(ind + 1, "asm volatile(\"\" : \"+v\"(" + v(t.a) + "));  // (pinned below the branch, as the leaves are)");
+        line(ind + 1, v(n) + " = " + post_expr(n) + ";");
+        line(ind, "} else {");
+        if (kind(n) == 2) line(ind + 1, v(n) + " = (na" + id + " ? " + v(t.a) + " : " + v(t.b) + ") - 0.0;");
+        else line(ind + 1, v(n) + " = (na" + id + " ? " + v(t.a) + " : -" + v(t.b) + ") + 0.0;");
+        line(ind, "}");
+    }
+    void emit_bounded(int ind, int n, const std::string &pt) {
+        value_nodes.pop_back();  // (bounded_eval lists the node itself)
+        std::vector<std::string> point_of(static_cast<size_t>(n_tree));
+        line(ind, "// bounded subtree at node " + std::to_string(n) + ": points, intervals, then only the operands that can matter");
+        bounded_points(ind, n, pt, point_of);
+        bounded_intervals(ind, n, point_of);
+        bounded_eval(ind, n, point_of);
+    }
+};
+
+bool emit_object(const std::vector<RmInstr> &prog, const std::vector<rmh::ProgTreeNode> &tree, int root, int index, bool prune, std::string &out) {
+    Gen g{prog.data(), tree.data(), static_cast<int>(tree.size())};
+    for (const rmh::ProgTreeNode &t : tree)
+        if (t.pre >= static_cast<int>(prog.size()) || t.main >= static_cast<int>(prog.size()) || t.a >= static_cast<int>(tree.size()) || t.b >= static_cast<int>(tree.size()))
+            return false;
+    g.prune = prune;
+    g.emit_node(1, root, "p");
+    if (!g.ok) return false;
+    out += "__device__ __forceinline__ double rm_rtc_obj_" + std::to_string(index) + "(float px, float py, float pz, double time) {\n";
+    for (int n : g.value_nodes) out += "    double v" + std::to_string(n) + " = 0.0;\n";
+    out += g.code + "    return v" + std::to_string(root) + ";\n}\n";
     return true;
 }
 
@@ -159,15 +393,13 @@ Rtc &rtc() {
 
 }  // namespace
 
-std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges) {
+std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges, const std::vector<rmh::ProgTreeNode> &tree,
+                         const std::vector<int32_t> &roots, bool prune) {
     const int n_obj = static_cast<int>(obj_ranges.size() / 2);
-    if (n_obj < 1 || n_obj > kMaxObjects || prog.size() > static_cast<size_t>(kMaxInstructions)) return std::string();
-    std::string out = "// generated by rm_rtc.cpp: the scene's expression programs, one function per object\nnamespace rmd {\n";
-    for (int r = 0; r < n_obj; ++r) {
-        const int first = obj_ranges[2 * r], count = obj_ranges[2 * r + 1];
-        if (first < 0 || count < 1 || static_cast<size_t>(first) + static_cast<size_t>(count) > prog.size()) return std::string();
-        if (!emit_object(prog.data() + first, count, r, out)) return std::string();
-    }
+    if (n_obj < 1 || n_obj > kMaxObjects || prog.size() > static_cast<size_t>(kMaxInstructions) || roots.size() != static_cast<size_t>(n_obj)) return std::string();
+    std::string out = "// generated by rm_rtc.cpp: the scene's expression trees, one function per object\nnamespace rmd {\n";
+    for (int r = 0; r < n_obj; ++r)
+        if (roots[r] < 0 || roots[r] >= static_cast<int>(tree.size()) || !emit_object(prog, tree, roots[r], r, prune, out)) return std::string();
     out += "__device__ __forceinline__ double rm_rtc_object_sdf(int obj, const Vec3f &p, double time) {\n    switch (obj) {\n";
     for (int r = 0; r < n_obj; ++r)
         out += "        case " + std::to_string(r) + ": return rm_rtc_obj_" + std::to_string(r) + "(p.x, p.y, p.z, time);\n";

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rm_scene_host.h"
 #include "rm_types.h"
 
 namespace rmrtc {
@@ -26,7 +27,9 @@ struct Kernel {
 // Straight-line source of a scene's programs: defines rmd::rm_rtc_object_sdf(int obj, const Vec3f &p, double time).
 // Empty when the forest is too large to be worth a compile (more than kMaxObjects objects or kMaxInstructions instructions).
 constexpr int kMaxObjects = 32, kMaxInstructions = 512;
-std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges);
+// `prune`: smooth unions / subtractions over spheres, boxes and tori skip operands that provably cannot matter (rm_rtc.cpp).
+std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges, const std::vector<rmh::ProgTreeNode> &tree,
+                         const std::vector<int32_t> &roots, bool prune);
 
 // hiprtc is loaded on first use (dlopen): false + reason when this machine has none.
 bool available(std::string *why);

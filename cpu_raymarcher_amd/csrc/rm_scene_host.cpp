@@ -897,7 +897,7 @@ struct Forest {
     }
     // post-order instruction stream of the subtree rooted at i, reading its point from slot `slot`
     mutable int max_slot = 0, max_vals = 0;
-    bool compile(int i, int slot, int &depth_vals, std::vector<RmInstr> &out, std::string &err) const {
+    bool compile(int i, int slot, int &depth_vals, std::vector<RmInstr> &out, std::string &err, std::vector<ProgTreeNode> &tree, int &tree_node) const {
         max_slot = std::max(max_slot, slot);
         if (slot + 1 >= RM_PROG_MAX_SLOTS) {
             err = "expression tree deeper than RM_PROG_MAX_SLOTS";
@@ -922,7 +922,11 @@ struct Forest {
         ins.op = d.type;
         ins.src = slot;
         ins.dst = slot + 1;
+        tree_node = static_cast<int>(tree.size());
+        tree.push_back(ProgTreeNode());
+        const int me = tree_node;
         if (d.type < 10) {
+            tree[me].main = static_cast<int>(out.size());
             out.push_back(ins);
             max_vals = std::max(max_vals, depth_vals + 1);
             if (++depth_vals > RM_PROG_MAX_VALS) {
@@ -942,12 +946,19 @@ struct Forest {
         };
         const bool pass_through = d.type >= 10 && d.type <= 12 && identity(ins.T) && identity(ins.Tinv) && plain_subtree(i);
         const int child_slot = pass_through ? slot : slot + 1;
-        if (!pass_through) out.push_back(ins);  // PRE
-        if (!compile(d.a, child_slot, depth_vals, out, err)) return false;
+        if (!pass_through) {
+            tree[me].pre = static_cast<int>(out.size());
+            out.push_back(ins);  // PRE
+        }
+        int child = -1;
+        if (!compile(d.a, child_slot, depth_vals, out, err, tree, child)) return false;
+        tree[me].a = child;
         const bool binary = d.type == 11 || d.type == 12;
-        if (binary && !compile(d.b, child_slot, depth_vals, out, err)) return false;
+        if (binary && !compile(d.b, child_slot, depth_vals, out, err, tree, child)) return false;
+        if (binary) tree[me].b = child;
         if (binary || d.type == 10) {
             ins.op = d.type + 10;  // POST
+            tree[me].main = static_cast<int>(out.size());
             out.push_back(ins);
             if (binary) --depth_vals;
         }
@@ -1116,7 +1127,9 @@ bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const i
         const int root = roots[r];
         const int first = static_cast<int>(s.prog.size());
         int vals = 0;
-        if (!f.compile(root, 0, vals, s.prog, err)) return false;
+        int tree_root = -1;
+        if (!f.compile(root, 0, vals, s.prog, err, s.prog_tree, tree_root)) return false;
+        s.prog_roots.push_back(tree_root);
         s.obj_ranges.push_back(first);
         s.obj_ranges.push_back(static_cast<int>(s.prog.size()) - first);
         // BoundingBox.fromPrimitive (boundingBox.ts:133-154) with the overridden getters

@@ -29,6 +29,13 @@ struct NodeDesc {
     double params[6];    // see RmInstr::p
 };
 
+// The expression tree behind an object's instruction stream (HostScene::prog), for the run-time specialiser (rm_rtc.h):
+// pre / main index the instructions of the node (-1: none -- an operator whose identity transform lets its operands read its
+// own point has no PRE half; Twist / Repetition / AnimatedTranslate have no POST half), a / b the operand nodes.
+struct ProgTreeNode {
+    int pre = -1, main = -1, a = -1, b = -1;
+};
+
 struct HostScene {
     int accel = 0;
     int preset = 0;
@@ -37,6 +44,8 @@ struct HostScene {
     int prog_slots = 1, prog_vals = 1;  // what the deepest program needs (device LDS sizing)
     std::vector<RmInstr> prog;
     std::vector<int32_t> obj_ranges;  // (first, count) per scene object
+    std::vector<ProgTreeNode> prog_tree;  // nodes of every object's tree (instruction indices into prog)
+    std::vector<int32_t> prog_roots;      // root node per scene object
     std::vector<RmPrim> prims;
     std::vector<float> world_pos; // Primitive.getWorldPosition() per primitive (BVH sort key)
     bool leaf_order = false;      // BVH sphere scenes: spheres / radii are stored in leaf order, bvh_prims is 0..n-1

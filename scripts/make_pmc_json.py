@@ -18,11 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def per_launch(out_dir, name, kernel_substr="render_kernel"):
+RENDER_KERNELS = ("render_kernel", "rm_rtc_render")  # the AOT kernels and a scene's run-time specialised one (rm_rtc.h)
+
+
+def per_launch(out_dir, name, kernel_substr=RENDER_KERNELS):
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for f in glob.glob(os.path.join(out_dir, name, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel_substr not in r.get("Kernel_Name", ""):
+            if not any(k in r.get("Kernel_Name", "") for k in ((kernel_substr,) if isinstance(kernel_substr, str) else kernel_substr)):
                 continue
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             n[r["Counter_Name"]] += 1
@@ -40,7 +43,7 @@ def main():
     kstats = []
     for f in sorted(glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)):
         kstats = [r for r in csv.DictReader(open(f))]
-    render = [r for r in kstats if "render_kernel" in r.get("Name", "")]
+    render = [r for r in kstats if any(k in r.get("Name", "") for k in RENDER_KERNELS)]
     kernel_name = render[0]["Name"] if render else None
     kernel_ms = float(render[0]["AverageNs"]) * 1e-6 if render else None
     args = open(os.path.join(out_dir, "bench_args.txt")).read().split()

@@ -1018,8 +1018,25 @@ def test_device_jsmath_is_bit_identical_to_the_oracle(gpu_ctx, oracle):
         assert same.all(), (fn, int((~same).sum()), a[~same][:3], got[~same][:3], want[~same][:3])
 
 
+@pytest.fixture(params=[1, 0], ids=["specialised", "interpreter"])
+def specialise(request, gpu_ctx):
+    """Expression forests run as this scene's run-time compiled kernel (rm_rtc.h; the default) or through the device
+    interpreter of rm_program.h (option `specialise` = 0): both must equal the oracle."""
+    gpu_ctx.set_option("specialise", request.param)
+    yield request.param
+    gpu_ctx.set_option("specialise", 1)
+
+
+def _assert_program_kernel(gpu_ctx, specialise, what):
+    k = gpu_ctx.last_kernel()
+    if specialise:
+        assert k.startswith("rm_rtc_render<"), (what, k, gpu_ctx.rtc_status())
+    else:
+        assert k.startswith("render_kernel<") and k.split(">")[0].endswith((", 2", ", 3")), (what, k)
+
+
 @pytest.mark.parametrize("preset", [6, 10, 11, 12, 13, 14, 15, 16, 17, 18])
-def test_operator_and_mandelbulb_presets(rm, gpu_ctx, oracle, preset):
+def test_operator_and_mandelbulb_presets(rm, gpu_ctx, oracle, specialise, preset):
     W, H = (120, 80) if preset == 13 else (200, 120)
     for accel in ("None", "BVH", "Octree"):
         for alg, tm, ang in (("sphere-tracer", 0.0, (0.0, 0.0)), ("adaptive-step-v3", 1234.5, (0.3, 0.8)),
@@ -1027,8 +1044,11 @@ def test_operator_and_mandelbulb_presets(rm, gpu_ctx, oracle, preset):
             if preset == 13 and alg == "fixed-step" and accel != "None":
                 continue  # the Mandelbulb costs 80 escape iterations per evaluation on the oracle side
             got = gpu_render(rm, gpu_ctx, preset, accel, W, H, ang, algorithm=alg, time=tm)
+            _assert_program_kernel(gpu_ctx, specialise, (preset, accel, alg))
             want = cpu_render(oracle, preset, accel, W, H, ang, algorithm=alg, time=tm)
             assert_same(got, want, "preset %d %s %s t=%g" % (preset, accel, alg, tm))
+    done, failed, log = gpu_ctx.rtc_status()
+    assert failed == 0, log
 
 
 def _random_forest(rng, n_roots):
@@ -1064,7 +1084,7 @@ def _random_forest(rng, n_roots):
     return [tree(4) for _ in range(n_roots)]
 
 
-def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, oracle):
+def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, oracle, specialise):
     rng = np.random.default_rng(5)
     for trial, n_roots in enumerate((1, 3, 7)):
         forest = _random_forest(rng, n_roots)
@@ -1073,6 +1093,7 @@ def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, orac
             osc.set_angles(0.2, -0.7)
             want = osc.render(160, 100, time=500.0)
             got = gpu_render(rm, gpu_ctx, None, accel, 160, 100, (0.2, -0.7), nodes=osc.nodes(), time=500.0)
+            _assert_program_kernel(gpu_ctx, specialise, (trial, accel))
             assert_same(got, want, "forest %d %s" % (trial, accel))
         sc = rm.Scene("BVH", ctx=gpu_ctx)
         osc = oracle.OracleScene(accel="BVH", prims=forest)
@@ -1083,6 +1104,74 @@ def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, orac
         for k in range(0, 300, 3):
             wd, wc = osc.distance(pts[k], time=250.0)
             assert (d[k] == wd or (np.isnan(d[k]) and np.isnan(wd))) and c[k] == wc, (trial, k, d[k], wd)
+
+
+def _plain_forest(rng, n_roots, depth, k_range):
+    """Spheres, boxes and tori (half of them rotated) under Round / SmoothUnion / SmoothSubtraction only: the trees whose
+    specialised code prunes operands by binary32 intervals (csrc/rm_rtc.cpp)."""
+    def leaf():
+        kind = rng.choice(["sphere", "box", "torus"], p=[0.3, 0.5, 0.2])
+        d = {"type": str(kind), "pos": [float(np.float32(v)) for v in rng.uniform(-0.9, 0.9, 3)],
+             "rot": [float(np.float32(v)) for v in rng.uniform(-3, 3, 3)] if rng.random() < 0.5 else None}
+        if kind == "sphere":
+            d["r"] = float(rng.uniform(0.1, 0.4))
+        elif kind == "box":
+            d["half"] = [float(np.float32(v)) for v in rng.uniform(0.02, 0.4, 3)]
+        else:
+            d["radius"] = float(rng.uniform(0.15, 0.4))
+        return d
+
+    def tree(dep):
+        if dep == 0 or (dep < depth and rng.random() < 0.15):
+            return leaf()
+        op = rng.choice(["round", "smoothUnion", "smoothSub"], p=[0.2, 0.6, 0.2]) if dep < depth else "smoothUnion"
+        if op == "round":
+            return {"type": "round", "a": tree(dep - 1), "radius": float(rng.uniform(0.005, 0.1))}
+        return {"type": str(op), "a": tree(dep - 1), "b": tree(dep - 1), "k": float(np.exp(rng.uniform(*np.log(k_range))))}
+
+    return [tree(depth) for _ in range(n_roots)]
+
+
+@pytest.mark.parametrize("seed,n_roots,depth,k_range", [(11, 1, 4, (2e-5, 2e-3)), (12, 2, 3, (1e-3, 0.05)), (13, 1, 5, (1e-4, 0.3)), (14, 3, 3, (1e-5, 1e-4))])
+def test_pruned_smooth_trees_equal_the_oracle(rm, gpu_ctx, oracle, seed, n_roots, depth, k_range):
+    """Exact pruning (rm_rtc.cpp): narrow and wide blends, unions and subtractions, rotated leaves -- renders and point
+    queries (surface points and blend seams among them) equal the oracle's, and equal the unpruned specialised code."""
+    rng = np.random.default_rng(seed)
+    forest = _plain_forest(rng, n_roots, depth, k_range)
+    osc = oracle.OracleScene(accel="BVH", prims=forest)
+    gpu_ctx.set_option("specialise", 1)
+    sc = rm.Scene("BVH", ctx=gpu_ctx)
+    sc.loadNodes(*osc.nodes())
+    assert "bounded subtree" in gpu_ctx.rtc_source(), "the forest was meant to exercise the pruning code"
+    for accel in ("BVH", "None"):
+        o2 = oracle.OracleScene(accel=accel, prims=forest)
+        o2.set_angles(0.25, 0.9)
+        want = o2.render(200, 120)
+        got = gpu_render(rm, gpu_ctx, None, accel, 200, 120, (0.25, 0.9), nodes=o2.nodes())
+        assert gpu_ctx.last_kernel().startswith("rm_rtc_render<")
+        assert_same(got, want, "plain forest %d %s" % (seed, accel))
+    # point queries: random points, then points walked onto the surface (where neighbouring leaves are closest to each other)
+    sc = rm.Scene("BVH", ctx=gpu_ctx)
+    sc.loadNodes(*osc.nodes())
+    pts = rng.uniform(-1.5, 1.5, (4000, 3)).astype(np.float32)
+    d, c = sc.getDistances(pts)
+    for _ in range(6):  # crude sphere tracing along a random direction towards the surface
+        dirs = rng.normal(size=pts.shape)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        pts = (pts + dirs * np.clip(d, -1, 1)[:, None] * 0.9).astype(np.float32)
+        d, c = sc.getDistances(pts)
+    gpu_ctx.set_option("prune", 0)
+    try:
+        sc2 = rm.Scene("BVH", ctx=gpu_ctx)
+        sc2.loadNodes(*osc.nodes())
+        assert "bounded subtree" not in gpu_ctx.rtc_source()
+        d2, c2 = sc2.getDistances(pts)
+    finally:
+        gpu_ctx.set_option("prune", 1)
+    assert (d.view(np.uint64) == d2.view(np.uint64)).all() and (c == c2).all(), int((d.view(np.uint64) != d2.view(np.uint64)).sum())
+    for k in range(0, len(pts), 40):
+        wd, wc = osc.distance(pts[k])
+        assert d[k] == wd and c[k] == wc, (seed, k, d[k], wd)
 
 
 @pytest.fixture

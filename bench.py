@@ -75,7 +75,7 @@ WORKLOADS = {
     "N3mixed": dict(name="N3: 40 synthetic mixed primitives (spheres, boxes, tori, rotated), 3840x2160, "
                          "sphere-tracing + BVH, Phong shader",
                     mixed=40, accel="BVH", width=3840, height=2160, shader="phong"),
-    # SDF operators / Mandelbulb through the expression-program interpreter
+    # SDF operators / Mandelbulb: the scene's trees compiled into the kernel at run time (rm_rtc.h; --opt specialise=0: the interpreter)
     "N4chicken": dict(name="N4: Chicken (preset 17: nine nested smooth unions over ten boxes), 3840x2160, "
                            "sphere-tracing + BVH, Phong shader",
                       preset=17, accel="BVH", width=3840, height=2160, shader="phong"),

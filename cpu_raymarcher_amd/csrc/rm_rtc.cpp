@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -424,7 +425,20 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
         log = "no specialised source for this scene";
         return false;
     }
-    const std::string main_src = "#define RM_RTC 1\n#define RM_RTC_ACCEL " + std::to_string(accel == 1 || accel == 2 ? accel : 0) + "\n#define RM_RTC_OTHER " +
+    // RM_RTC_DEFINES (environment; experiments only): names to #define ahead of the sources, separated by blanks
+    std::string extra;
+    if (const char *env = std::getenv("RM_RTC_DEFINES")) {
+        std::string word;
+        for (const char *c = env;; ++c) {
+            if (*c && *c != ' ') word += *c;
+            else {
+                if (!word.empty()) extra += "#define " + word + " 1\n";
+                word.clear();
+                if (!*c) break;
+            }
+        }
+    }
+    const std::string main_src = extra + "#define RM_RTC 1\n#define RM_RTC_ACCEL " + std::to_string(accel == 1 || accel == 2 ? accel : 0) + "\n#define RM_RTC_OTHER " +
                                  (other ? "1" : "0") + "\n" + (length_sqrt ? "#define RM_LENGTH_SQRT 1\n" : "") + "#include \"rm_kernels.hip\"\n";
     const char *names[] = {"rm_kernels.hip", "rm_device.h", "rm_jsmath.h", "rm_types.h", "rm_program.h", "rm_bvh_list.h", "rm_kernels.h", "rm_diag.h",
                            "rm_rtc_scene.inc"};

@@ -374,11 +374,17 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *   n0_batch 1..64 BVH (v2): getNormal is deferred until no lane of the wave needs a march distance, then evaluated for all waiting
  *                 rays in one round, the three offset samples taken from the sphere that gave d0 where provably the minimum;
  *                 lanes waiting that trigger that round early (64: never early; default 64)
- *   lpt 0|1       v2: hand out a launch's work items longest-first using the item costs the previous launch recorded (any
- *                 order gives the same bytes; default 0 since round 3: the in-round march steps took the slowest items' edge)
+ *   lpt 0|1       v2: hand out a launch's work items longest-first using the item durations the previous launch recorded (any
+ *                 order gives the same bytes; default 1: a frame alone 1.07 against 1.14 ms; bench.py turns it off with frames in flight)
  *   multi_step 0|1  v2 BVH: a lane takes further march steps inside a round while the leaf set and the winning sphere provably
  *                 stay the same (default 1; same bytes either way)
  *   lds_fill 0|1  v2: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU (default 0; measurement knob)
+ *   item_wide 0|1 v2: the 64-pixel batches of a work item side by side (item = tile_w * item_px / 64 pixels wide) instead of one
+ *                 above the other (default 0: measured no gain in write traffic, 2 % slower with frames in flight)
+ *   specialise 0|1  expression forests: 1 (default) = the scene's trees compiled into the kernel at run time (rm_rtc_* above),
+ *                 0 = the device interpreter of csrc/rm_program.h
+ *   prune 0|1     specialised kernels: smooth unions / subtractions over spheres, boxes and tori skip operands whose binary32
+ *                 interval proves they cannot matter (exact: csrc/rm_rtc.cpp; default 1; read when a scene is built)
  *   v1_lists 0|1  v1 BVH kernels: per-ray hit-leaf lists (as v2) instead of one tree walk per interval advance (default 1)
  *   v1_block 64|128|256  v1 kernels: threads per workgroup (default 64: one wave, so wave slots refill one by one); without an
  *                 explicit tile_w the v1 kernels use 8 x 8-pixel wave tiles

@@ -3,7 +3,7 @@
 # are stamped with the kernel sources' hash and bench.py refuses stale ones).  Started by scripts/gpu_battery.sh, which
 # leaves the commit in .build_commit for the stamps.
 #   0. scripts/bin/valu_issue_bench                                          -> profiles/<round>/valu_issue_costs.json
-#   1. scripts/profile_round.sh for C3, C2, C5 (kernel trace + PMC passes)   -> profiles/<round>/pmc_<W>.{json,txt}
+#   1. scripts/profile_round.sh for C3, C2, C5, N4chicken (kernel trace + PMC passes)   -> profiles/<round>/pmc_<W>.{json,txt}
 #   2. the bench lines                                                       -> profiles/<round>/bench_*.json
 #   3. scripts/shard_overhead.py (N = 2, 4, 8; C3 and C5)                    -> profiles/<round>/shard_overhead.txt
 # Everything is copied to gpurun_out/<round>/ as well (gpurun merges only gpurun_out/ back).
@@ -17,7 +17,7 @@ O=gpurun_out/$RM_ROUND; mkdir -p $O $P
 if [ -x scripts/bin/valu_issue_bench ]; then
   timeout -k 10 300 scripts/bin/valu_issue_bench > $P/valu_issue_costs.json 2> $O/valu_issue_bench.err || echo "valu_issue_bench failed"
 fi
-for w in C3 C2 C5; do
+for w in C3 C2 C5 N4chicken; do
   scripts/profile_round.sh $w > gpurun_out/profile_$w.log 2>&1 || echo "profile $w failed"
   tail -1 gpurun_out/profile_$w.log
   cp $(ls -S gpurun_out/prof_${RM_ROUND}_$w/trace/*/*kernel_stats.csv | head -1) $P/kernel_stats_$w.csv 2>/dev/null || true
@@ -46,6 +46,9 @@ line C5 --workload C5
 if [ "$1" != quick ]; then
   line C3_sqrt --opt length=1 --no-cpu-baseline
   for w in N3 N3mixed N4chicken N4screw N4mandelbulb; do line $w --workload $w --no-cpu-baseline; done
+  # the same scenes through the device interpreter (the run-time specialiser off) and the specialised code without pruning
+  for w in N4chicken N4screw N4mandelbulb; do line ${w}_interpreter --workload $w --opt specialise=0 --no-cpu-baseline; done
+  line N4chicken_unpruned --workload N4chicken --opt prune=0 --no-cpu-baseline
   line analytics_sweep --analytics-sweep --steps 60 --no-cpu-baseline
   timeout -k 10 300 python scripts/shard_overhead.py 240 N=2 N=4 N=8 > $P/shard_overhead.txt 2>&1 || true
   timeout -k 10 300 python scripts/shard_overhead.py 120 N=8 WL=C5 >> $P/shard_overhead.txt 2>&1 || true

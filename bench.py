@@ -733,6 +733,17 @@ def main():
             torch.cuda.synchronize()
             out["gathered_frame_equals_single_gpu_frame"] = all(bool(torch.equal(asm.frame[s], full[s])) for s in asm.frame)
             out["combined_diagnostics_equal_single_gpu_diagnostics"] = ctx.decode_acc(whole) == d
+            if "golden" in wl and not args.no_verify:  # ... and the committed fixture (C = JS oracle agreement, tests/golden/)
+                with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                    g = json.load(f)[wl["golden"]]
+                ok = wl["shader"] == "phong" or hashlib.sha256(asm.frame["rgba"].cpu().numpy().tobytes()).hexdigest() == g["sha256"]["rgba"]
+                gd = g.get("diagnostics")
+                ok = ok and (not gd or all(d[key] == gd[key] for key in ("total_sdf", "total_iters", "max_sdf", "min_sdf")))
+                out["frames_verified"] = 1 if ok else 0
+                out["frames_verified_how"] = ("SHA-256 of the gathered, reassembled RGBA frame and the combined diagnostics of the last frame of the "
+                                              "timed region against tests/golden/golden.json[%s]" % wl["golden"])
+                if not ok:
+                    raise SystemExit("bench.py: the gathered frame or its diagnostics differ from the golden fixture %s" % wl["golden"])
         if world == 1 and args.analytics_sweep:
             out["config"]["camera"] = {"pitch": 0.0, "yaw": "+0.015 rad per frame (analytics sweep)"}
             out["analytics_series"] = [

@@ -391,7 +391,8 @@ int upload_vec(rm_ctx *ctx, const std::vector<T> &v, T **out) {
 }
 
 int upload_scene(rm_ctx *ctx) {
-    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges, ctx->host.prog_tree, ctx->host.prog_roots, ctx->opt_prune != 0)
+    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges, ctx->host.prog_tree, ctx->host.prog_roots, ctx->opt_prune != 0, ctx->host.bvh,
+                                                              ctx->host.bvh_prims)
                                      : std::string();
     if (!ctx->has_device) {
         free_device_scene(ctx);

@@ -174,6 +174,9 @@ __device__ double all_prims_distance(const RmRenderParams &P, const Vec3f &p, ui
 // every leaf whose box contains p (a primitive lives in exactly one leaf), else all.
 template <int GEN>
 __device__ double bvh_distance(const RmRenderParams &P, const Vec3f &p, uint32_t &count) {
+#ifdef RM_RTC_BVH_LEAVES  // this scene's leaves are code (rm_rtc.cpp, emit_bvh): no node loads, the objects called by name
+    if (GEN == 4) return rm_rtc_bvh_distance(p, P.time, count);
+#endif
     double closest = RM_MAX_DIST;
     uint32_t found = 0;
     int i = 0;
@@ -379,6 +382,9 @@ __device__ __forceinline__ double scene_distance(const RmRenderParams &P, const 
 // in traversal order -- by one stackless traversal, so no per-ray list is stored.
 __device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, const RayInv &ri, double keyT, int keyOrd,
                                   Interval &out) {
+#ifdef RM_RTC_BVH_LEAVES
+    return rm_rtc_bvh_next_interval(r, ri, keyT, keyOrd, out);
+#else
     bool have = false;
     int i = 0;
     const int n = P.bvh_nodes;
@@ -409,6 +415,7 @@ __device__ bool bvh_next_interval(const RmRenderParams &P, const Ray &r, const R
         i = node.skip;
     }
     return have;
+#endif
 }
 
 // ------------------------------------------------------------------ the render kernel

@@ -28,8 +28,9 @@ struct Kernel {
 // Empty when the forest is too large to be worth a compile (more than kMaxObjects objects or kMaxInstructions instructions).
 constexpr int kMaxObjects = 32, kMaxInstructions = 512;
 // `prune`: smooth unions / subtractions over spheres, boxes and tori skip operands that provably cannot matter (rm_rtc.cpp).
+// bvh / bvh_prims: the scene's BVH (may be empty); up to eight leaves are emitted as code (rm_rtc_bvh_distance / _next_interval).
 std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges, const std::vector<rmh::ProgTreeNode> &tree,
-                         const std::vector<int32_t> &roots, bool prune);
+                         const std::vector<int32_t> &roots, bool prune, const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &bvh_prims);
 
 // hiprtc is loaded on first use (dlopen): false + reason when this machine has none.
 bool available(std::string *why);

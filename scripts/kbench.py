@@ -26,6 +26,10 @@ WL = {
     "N4chicken": dict(preset=17, accel="BVH", W=3840, H=2160, shader="phong"),
     "N4screw": dict(preset=16, accel="BVH", W=3840, H=2160, shader="phong"),
     "N4mandel": dict(preset=13, accel="BVH", W=1920, H=1080, shader="phong"),
+    "P0": dict(preset=0, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P0none": dict(preset=0, accel="None", W=3840, H=2160, shader="phong"),
+    "N4screwNone": dict(preset=16, accel="None", W=3840, H=2160, shader="phong"),
+    "N4screwOct": dict(preset=16, accel="Octree", W=3840, H=2160, shader="phong"),
     "N4sixty7": dict(preset=18, accel="BVH", W=3840, H=2160, shader="phong"),
     "N4smooth": dict(preset=11, accel="BVH", W=3840, H=2160, shader="phong"),
 }

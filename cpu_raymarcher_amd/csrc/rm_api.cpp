@@ -139,6 +139,9 @@ struct rm_ctx {
     // rendered with, compiled at its first launch (1.5 - 3 s, synchronous) and kept until the scene is replaced.  A compile
     // that fails is remembered with its log (rm_rtc_status) and the interpreter of rm_program.h serves the scene.
     int64_t opt_specialise = 1;
+    // sphere lists of fewer spheres than this run in the one-ray-per-lane kernels as the scene's own code (C2, nine spheres at
+    // 1080p: 0.22 ms alone against 0.32 in the v2 wave loop, 8 780 against 8 340 frames/s in flight); without hiprtc the rule is < 8
+    int64_t opt_rtc_spheres = 16;
     int64_t opt_prune = 1;  // specialised kernels: exact pruning of smooth unions / subtractions (rm_rtc.cpp); takes effect at the next scene build
     std::string rtc_src;
     std::map<int, rmrtc::Kernel> rtc_kernels;
@@ -179,7 +182,7 @@ int hip_fail(rm_ctx *ctx, hipError_t e, const char *what) {
 // the kernels exist twice: vec3.length = Math.hypot, and = sqrt(x*x + y*y + z*z) (rm_kernels.h, option `length`)
 // the scene's specialised kernel for (accel, marcher family, length form), compiled on first use; nullptr: the interpreter serves
 const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
-    if (!ctx->opt_specialise || !ctx->host.program || ctx->rtc_src.empty() || !ctx->has_device) return nullptr;
+    if (!ctx->opt_specialise || ctx->rtc_src.empty() || !ctx->has_device) return nullptr;
     const int key = (accel * 2 + (other ? 1 : 0)) * 2 + (ctx->opt_length ? 1 : 0);
     auto it = ctx->rtc_kernels.find(key);
     if (it != ctx->rtc_kernels.end()) return &it->second;
@@ -194,10 +197,12 @@ const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
 
 hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
-    const rmrtc::Kernel *special = p.general >= 2 ? specialised_kernel(ctx, p.accel, p.algorithm != 0) : nullptr;
+    // every launch of the one-ray-per-lane kernels (not the v2 wave loop, not the lean octree kernel) takes the scene's own kernel if it has one
+    const bool lean_oct = p.accel == 1 && p.oct_lean && !p.general && p.algorithm == 0 && p.oct_lut && p.oct_recs && p.filter;
+    const rmrtc::Kernel *special = (p.variant == 2 && p.algorithm == 0) || lean_oct ? nullptr : specialised_kernel(ctx, p.accel, p.algorithm != 0);
     p.rtc_function = special ? special->render : nullptr;
     rm_ctx::OctFrameSlot *oct_slot = nullptr;
-    if (p.accel == 1 && p.oct_lean && !p.general && p.algorithm == 0 && p.oct_lut && p.oct_recs && p.filter) {
+    if (lean_oct) {
         const size_t n = static_cast<size_t>(p.oct_nodes);
         auto matches = [&](const rm_ctx::OctFrameSlot &sl) {
             return sl.valid && sl.gen == ctx->scene_gen && sl.origin[0] == p.origin_d[0] && sl.origin[1] == p.origin_d[1] && sl.origin[2] == p.origin_d[2];
@@ -391,9 +396,20 @@ int upload_vec(rm_ctx *ctx, const std::vector<T> &v, T **out) {
 }
 
 int upload_scene(rm_ctx *ctx) {
-    ctx->rtc_src = ctx->host.program ? rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges, ctx->host.prog_tree, ctx->host.prog_roots, ctx->opt_prune != 0, ctx->host.bvh,
-                                                              ctx->host.bvh_prims)
-                                     : std::string();
+    // Scenes the one-ray-per-lane kernels serve and that are small enough to be code (rm_rtc.h): expression forests, and --
+    // as one single-leaf object per primitive -- primitive lists (up to 32) and sphere lists of fewer than `rtc_spheres` (16)
+    // spheres, whose BVH has at most eight leaves (larger ones run in the v2 wave loop).
+    ctx->rtc_src.clear();
+    if (ctx->host.program) {
+        ctx->rtc_src = rmrtc::scene_source(ctx->host.prog, ctx->host.obj_ranges, ctx->host.prog_tree, ctx->host.prog_roots, ctx->opt_prune != 0, ctx->host.bvh,
+                                           ctx->host.bvh_prims, false);
+    } else if (ctx->host.general ? ctx->host.prims.size() <= 32 : static_cast<int64_t>(ctx->host.spheres.size()) < ctx->opt_rtc_spheres) {
+        std::vector<RmInstr> prog;
+        std::vector<int32_t> ranges, roots;
+        std::vector<rmh::ProgTreeNode> tree;
+        if (rmh::leaf_objects(ctx->host, prog, ranges, tree, roots))
+            ctx->rtc_src = rmrtc::scene_source(prog, ranges, tree, roots, false, ctx->host.bvh, ctx->host.bvh_prims, true);
+    }
     if (!ctx->has_device) {
         free_device_scene(ctx);
         return RM_OK;
@@ -615,7 +631,11 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     // auto: the octree runs in the one-ray-per-lane kernels; so do the smallest scenes.  (Until round 2 the 9-sphere grid of C2
     // was faster there too; since the in-round march steps of round 3 the uniform wave loop wins it: 0.308 against 0.331 ms
     // alone, 9 680 against 8 920 frames/s in flight.)
-    if (p.variant == 0) p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 8) ? 1 : 2;
+    if (p.variant == 0)
+        p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 8 ||
+                     (ctx->opt_specialise && !ctx->rtc_src.empty() && static_cast<int64_t>(ctx->host.spheres.size()) < ctx->opt_rtc_spheres))
+                        ? 1
+                        : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
     if (ctx->host.general) p.variant = 1;                    // so do boxes, tori and rotated primitives
     // v1: square 8 x 8 wave tiles keep a wave's rays in the same leaves / intervals (N3-mixed 2.31 -> 2.07 ms together with
@@ -1207,7 +1227,7 @@ int rm_scene_distance(rm_ctx *ctx, const float *points_xyz, int64_t n, double *d
     p.oct = ctx->dev.oct;
     p.oct_prims = ctx->dev.oct_prims;
     p.oct_lut = ctx->opt_lut ? ctx->dev.oct_lut : nullptr;
-    if (p.general >= 2) {
+    {
         const rmrtc::Kernel *special = specialised_kernel(ctx, p.accel, false);
         p.rtc_function = special ? special->distance : nullptr;
     }
@@ -1448,6 +1468,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         ctx->opt_prune = value ? 1 : 0;
         return RM_OK;
     }
+    if (!std::strcmp(key, "rtc_spheres")) {
+        if (value < 0 || value > 33) return fail(ctx, RM_E_INVALID, "rtc_spheres must be 0..33");
+        ctx->opt_rtc_spheres = value;
+        return RM_OK;
+    }
     if (!std::strcmp(key, "specialise")) {
         ctx->opt_specialise = value ? 1 : 0;
         return RM_OK;
@@ -1556,6 +1581,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
     else if (!std::strcmp(key, "specialise")) *value = ctx->opt_specialise;
+    else if (!std::strcmp(key, "rtc_spheres")) *value = ctx->opt_rtc_spheres;
     else if (!std::strcmp(key, "prune")) *value = ctx->opt_prune;
     else if (!std::strcmp(key, "item_wide")) *value = ctx->opt_item_wide;
     else if (!std::strcmp(key, "multi_step")) *value = ctx->opt_multi_step;

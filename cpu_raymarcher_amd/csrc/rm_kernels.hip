@@ -1255,11 +1255,11 @@ hipError_t RM_LEN_VARIANT(rm_launch_render)(const RmRenderParams &p, hipStream_t
     RmRenderParams pl = p;
     pl.v1_list_offset = -1;
     const size_t list_bytes = static_cast<size_t>(2) * RM_V1_LIST_CAP * threads;
-    if (p.accel == 2 && p.v1_lists && p.general < 2 && p.bvh_nodes < 65536 && shmem + list_bytes <= 64 * 1024) {
+    if (p.accel == 2 && p.v1_lists && p.general < 2 && !p.rtc_function && p.bvh_nodes < 65536 && shmem + list_bytes <= 64 * 1024) {
         pl.v1_list_offset = static_cast<int32_t>((shmem + 15) & ~static_cast<size_t>(15));  // per-ray hit-leaf lists behind the program slots
         shmem = static_cast<size_t>(pl.v1_list_offset) + list_bytes;
     }
-    if (p.general >= 2 && p.rtc_function) {  // this scene's run-time specialised kernel (rm_rtc.h): same grid, no interpreter state in LDS
+    if (p.rtc_function) {  // this scene's run-time specialised kernel (rm_rtc.h): same grid, nothing in LDS (set by the API layer for these launches only)
         size_t bytes = sizeof pl;
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(const_cast<void *>(p.rtc_function)), grid.x, 1, 1, block.x, 1, 1, 0, stream, nullptr,
@@ -1335,7 +1335,7 @@ hipError_t RM_LEN_VARIANT(rm_launch_distance)(const RmRenderParams &p, const flo
     if (n <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
     const size_t shmem = p.general >= 2 ? (static_cast<size_t>(p.prog_slots) * 12 + static_cast<size_t>(p.prog_vals) * 8) * 256 : 0;
-    if (p.general >= 2 && p.rtc_function) {  // rm_rtc_distance(RmRenderParams, const float *, int64_t, double *, uint32_t *)
+    if (p.rtc_function) {  // rm_rtc_distance(RmRenderParams, const float *, int64_t, double *, uint32_t *)
         struct Args {
             RmRenderParams p;
             const float *points;

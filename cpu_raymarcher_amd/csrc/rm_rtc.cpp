@@ -465,7 +465,7 @@ bool emit_bvh(const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &pri
 }  // namespace
 
 std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges, const std::vector<rmh::ProgTreeNode> &tree,
-                         const std::vector<int32_t> &roots, bool prune, const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &bvh_prims) {
+                         const std::vector<int32_t> &roots, bool prune, const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &bvh_prims, bool require_bvh) {
     const int n_obj = static_cast<int>(obj_ranges.size() / 2);
     if (n_obj < 1 || n_obj > kMaxObjects || prog.size() > static_cast<size_t>(kMaxInstructions) || roots.size() != static_cast<size_t>(n_obj)) return std::string();
     std::string out = "// generated by rm_rtc.cpp: the scene's expression trees, one function per object\nnamespace rmd {\n";
@@ -477,6 +477,7 @@ std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int
     out += "        default: return 0.0;\n    }\n}\n";
     std::string tree_code;
     if (emit_bvh(bvh, bvh_prims, n_obj, tree_code)) out += tree_code;
+    else if (require_bvh && !bvh.empty()) return std::string();
     out += "}  // namespace rmd\n";
     return out;
 }

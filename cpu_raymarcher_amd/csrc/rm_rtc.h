@@ -29,8 +29,11 @@ struct Kernel {
 constexpr int kMaxObjects = 32, kMaxInstructions = 512;
 // `prune`: smooth unions / subtractions over spheres, boxes and tori skip operands that provably cannot matter (rm_rtc.cpp).
 // bvh / bvh_prims: the scene's BVH (may be empty); up to eight leaves are emitted as code (rm_rtc_bvh_distance / _next_interval).
+// require_bvh: no source at all when a BVH is given and cannot be emitted (plain primitive lists: their data-driven kernels are
+// the better choice once the tree has to be walked in memory anyway).
 std::string scene_source(const std::vector<RmInstr> &prog, const std::vector<int32_t> &obj_ranges, const std::vector<rmh::ProgTreeNode> &tree,
-                         const std::vector<int32_t> &roots, bool prune, const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &bvh_prims);
+                         const std::vector<int32_t> &roots, bool prune, const std::vector<RmBvhNode> &bvh, const std::vector<int32_t> &bvh_prims,
+                         bool require_bvh);
 
 // hiprtc is loaded on first use (dlopen): false + reason when this machine has none.
 bool available(std::string *why);

@@ -1157,6 +1157,56 @@ bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const i
     return build_accel(s, n_roots, err);
 }
 
+bool leaf_objects(const HostScene &s, std::vector<RmInstr> &prog, std::vector<int32_t> &obj_ranges, std::vector<ProgTreeNode> &tree,
+                  std::vector<int32_t> &roots) {
+    prog.clear();
+    obj_ranges.clear();
+    tree.clear();
+    roots.clear();
+    if (s.program) return false;
+    const size_t n = s.general ? s.prims.size() : s.spheres.size();
+    if (n == 0 || (!s.general && s.radii.size() != n)) return false;
+    for (size_t i = 0; i < n; ++i) {
+        RmInstr ins;
+        std::memset(&ins, 0, sizeof ins);
+        if (s.general) {
+            const RmPrim &q = s.prims[i];
+            std::memcpy(ins.T, q.m, sizeof ins.T);
+            ins.op = q.type & 0xFF;
+            if (ins.op == 1) for (int k = 0; k < 3; ++k) ins.p[k] = q.half[k];  // Float32Array members (box.ts:8-11)
+            else ins.p[0] = q.a, ins.p[1] = q.b;
+        } else {
+            make_transform(s.spheres[i].cx, s.spheres[i].cy, s.spheres[i].cz, nullptr, ins.T);  // sceneManager.ts:21-37 without a rotation
+            ins.op = 0;
+            ins.p[0] = s.radii[i];
+        }
+        if (ins.op < 0 || ins.op > 2) return false;
+        Mat4 inv = Mat4::identity();
+        invert4(ins.T, inv.m);
+        std::memcpy(ins.Tinv, inv.m, sizeof ins.Tinv);
+        for (int k = 0; k < 16; ++k)
+            if (!std::isfinite(ins.T[k]) || !std::isfinite(ins.Tinv[k])) return false;
+        for (int k = 0; k < 6; ++k)
+            if (!std::isfinite(ins.p[k])) return false;
+        auto affine = [](const float *m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; };
+        auto shift = [&](const float *m) {
+            return affine(m) && m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[6] == 0.0f &&
+                   m[8] == 0.0f && m[9] == 0.0f;
+        };
+        ins.flags = (affine(ins.T) ? 1 : 0) | (affine(ins.Tinv) ? 2 : 0) | (shift(ins.T) ? 4 : 0) | (shift(ins.Tinv) ? 8 : 0);
+        ins.src = 0;
+        ins.dst = 1;
+        ProgTreeNode t;
+        t.main = static_cast<int>(prog.size());
+        obj_ranges.push_back(static_cast<int32_t>(prog.size()));
+        obj_ranges.push_back(1);
+        roots.push_back(static_cast<int32_t>(tree.size()));
+        tree.push_back(t);
+        prog.push_back(ins);
+    }
+    return true;
+}
+
 void camera_from_angles(double pitch, double yaw, float rot9[9], float origin3[3]) {
     const double half_pi = 3.141592653589793 / 2;
     const double p = js_min2(js_max2(pitch, -half_pi), half_pi);  // camera.ts:59

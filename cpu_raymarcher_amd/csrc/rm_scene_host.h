@@ -117,6 +117,12 @@ bool preset_nodes(int index, std::vector<NodeDesc> &nodes, std::vector<int> &roo
 bool build_scene_nodes(HostScene &s, const NodeDesc *nodes, int n_nodes, const int *roots, int n_roots, int accel,
                        std::string &err);
 
+// A scene of plain primitives (spheres; spheres / boxes / tori with transforms) as one single-leaf expression object per
+// primitive, in the scene's primitive order -- what the run-time specialiser (rm_rtc.h) needs to emit such a scene as code.
+// False when the scene is an expression forest already, is empty, or holds a non-finite number.
+bool leaf_objects(const HostScene &s, std::vector<RmInstr> &prog, std::vector<int32_t> &obj_ranges, std::vector<ProgTreeNode> &tree,
+                  std::vector<int32_t> &roots);
+
 // gl-matrix mat4.scale(m, m, [x, y, z]) in place (sceneManager.ts:63: the Mandelbulb's world->local is post-scaled)
 void scale_transform(float m[16], double x, double y, double z);
 

@@ -383,6 +383,9 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *                 above the other (default 0: measured no gain in write traffic, 2 % slower with frames in flight)
  *   specialise 0|1  expression forests: 1 (default) = the scene's trees compiled into the kernel at run time (rm_rtc_* above),
  *                 0 = the device interpreter of csrc/rm_program.h
+ *   rtc_spheres 0..33  sphere lists of fewer spheres than this (default 16) and primitive lists of up to 32 primitives are compiled
+ *                 too, one single-leaf object per primitive, when their BVH has at most eight leaves (emitted as code: no node
+ *                 walks in memory); they then run in the one-ray-per-lane kernel instead of the v2 wave loop
  *   prune 0|1     specialised kernels: smooth unions / subtractions over spheres, boxes and tori skip operands whose binary32
  *                 interval proves they cannot matter (exact: csrc/rm_rtc.cpp; default 1; read when a scene is built)
  *   v1_lists 0|1  v1 BVH kernels: per-ray hit-leaf lists (as v2) instead of one tree walk per interval advance (default 1)

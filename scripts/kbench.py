@@ -27,6 +27,11 @@ WL = {
     "N4screw": dict(preset=16, accel="BVH", W=3840, H=2160, shader="phong"),
     "N4mandel": dict(preset=13, accel="BVH", W=1920, H=1080, shader="phong"),
     "P0": dict(preset=0, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P1": dict(preset=1, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P4": dict(preset=4, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P8": dict(preset=8, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P9": dict(preset=9, accel="BVH", W=3840, H=2160, shader="phong"),
+    "P9oct": dict(preset=9, accel="Octree", W=3840, H=2160, shader="phong"),
     "P0none": dict(preset=0, accel="None", W=3840, H=2160, shader="phong"),
     "N4screwNone": dict(preset=16, accel="None", W=3840, H=2160, shader="phong"),
     "N4screwOct": dict(preset=16, accel="Octree", W=3840, H=2160, shader="phong"),

@@ -47,6 +47,16 @@ def assert_same(got, want, what):
         assert bad == 0, "%s: %s differs in %d of %d entries" % (what, name, bad, w.size)
 
 
+@pytest.fixture(params=[1, 0], ids=["specialised", "ahead-of-time"])
+def specialise(request, gpu_ctx):
+    """Small scenes -- expression forests, plain primitive lists, fewer than eight spheres -- run as the scene's run-time
+    compiled kernel (rm_rtc.h; the default) or through the library's ahead-of-time kernels (the interpreter of rm_program.h for
+    forests; option `specialise` = 0): both must equal the oracle."""
+    gpu_ctx.set_option("specialise", request.param)
+    yield request.param
+    gpu_ctx.set_option("specialise", 1)
+
+
 def test_device_hypot_is_v8_math_hypot(rm, gpu_ctx, oracle):
     rng = np.random.default_rng(11)
     xyz = (rng.standard_normal((300000, 3)) * 3).astype(np.float32)
@@ -381,8 +391,10 @@ def test_degenerate_radii(rm, gpu_ctx, oracle, accel):
 
 @pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
 @pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])
-def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):
+def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, specialise, preset, accel):
     got = gpu_render(rm, gpu_ctx, preset, accel, 200, 150)
+    if preset in (0, 1, 4) and not (accel == "Octree"):  # fewer than eight spheres: the one-ray-per-lane kernels, the scene's own by default
+        assert gpu_ctx.last_kernel().startswith("rm_rtc_render<" if specialise else "render_kernel<"), gpu_ctx.last_kernel()
     assert_same(got, cpu_render(oracle, preset, accel, 200, 150), "preset %d %s" % (preset, accel))
 
 
@@ -391,7 +403,7 @@ def test_every_sphere_preset_and_accel(rm, gpu_ctx, oracle, preset, accel):
                                                  ("adaptive-step", None, None), ("adaptive-step-v2", None, None),
                                                  ("adaptive-step-v2", 1.8, None), ("adaptive-step-v3", None, None),
                                                  ("adaptive-step-v3", 1.05, None)])
-def test_other_marchers(rm, gpu_ctx, oracle, accel, alg, overshoot, step):
+def test_other_marchers(rm, gpu_ctx, oracle, specialise, accel, alg, overshoot, step):
     """The rest of the Algorithm plugin (raymarchWorker.ts:49-68): same accel prologue / skip
     protocol, different step rule; counters and G-buffers bit-exact against the oracle."""
     for preset, ang in ((3, (0.2, 0.5)), (1, (0.0, 0.0))):
@@ -930,11 +942,12 @@ def test_analytics_sweep_frames(rm, gpu_ctx, oracle):
 
 @pytest.mark.parametrize("accel", ["None", "BVH", "Octree"])
 @pytest.mark.parametrize("preset", [5, 7, 8, 9])
-def test_box_and_torus_presets(rm, gpu_ctx, oracle, preset, accel):
+def test_box_and_torus_presets(rm, gpu_ctx, oracle, specialise, preset, accel):
     """Torus (rotated), Cube, Sphere and Cube, Pyramid of Boxes -- general
     transformMat4, Box / Torus localSdf, bounds from the inverted matrix."""
     for alg, ang in (("sphere-tracer", (0.3, -0.8)), ("adaptive-step-v3", (-0.5, 2.4))):
         got = gpu_render(rm, gpu_ctx, preset, accel, 220, 140, ang, algorithm=alg)
+        assert gpu_ctx.last_kernel().startswith("rm_rtc_render<" if specialise else "render_kernel<"), gpu_ctx.last_kernel()
         assert_same(got, cpu_render(oracle, preset, accel, 220, 140, ang, algorithm=alg), "preset %d %s %s" % (preset, accel, alg))
 
 
@@ -1016,15 +1029,6 @@ def test_device_jsmath_is_bit_identical_to_the_oracle(gpu_ctx, oracle):
         got = gpu_ctx.selftest_jsmath(fn, a, b)
         same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), (fn, int((~same).sum()), a[~same][:3], got[~same][:3], want[~same][:3])
-
-
-@pytest.fixture(params=[1, 0], ids=["specialised", "interpreter"])
-def specialise(request, gpu_ctx):
-    """Expression forests run as this scene's run-time compiled kernel (rm_rtc.h; the default) or through the device
-    interpreter of rm_program.h (option `specialise` = 0): both must equal the oracle."""
-    gpu_ctx.set_option("specialise", request.param)
-    yield request.param
-    gpu_ctx.set_option("specialise", 1)
 
 
 def _assert_program_kernel(gpu_ctx, specialise, what):

@@ -36,10 +36,12 @@ def test_option_default_and_sources(host_ctx):
     for preset in range(19):
         host_ctx.scene_from_preset(preset, 2)
         src = host_ctx.rtc_source()
-        if preset in PROGRAM_PRESETS:
+        if preset == 3:  # 125 spheres: the v2 wave loop's scene
+            assert src == "", preset
+        else:  # expression forests, and plain primitives / fewer than sixteen spheres as one single-leaf object each
             assert "rm_rtc_object_sdf" in src and "rm_rtc_obj_0" in src, preset
-        else:
-            assert src == "", preset  # spheres and plain primitives have kernels of their own
+            if preset != 15:  # (Repetition's bounding box is infinite: that tree stays data)
+                assert "RM_RTC_BVH_LEAVES" in src and "rm_rtc_bvh_distance" in src, preset  # the handful of BVH leaves as code
     host_ctx.scene_from_preset(17, 2)  # the Chicken: ten boxes, nine smooth unions, every literal exact (hexadecimal floating point)
     src = host_ctx.rtc_source()
     assert src.count("leaf_box(") == 10 and src.count("post_smooth_union(") == 9 and "0x1.a36e2eb1c432dp-14" in src
@@ -51,7 +53,13 @@ def test_forests_beyond_the_limits_keep_the_interpreter(host_ctx):
     host_ctx.scene_from_nodes(nodes, list(range(40)), 2)  # 40 objects > 32
     assert host_ctx.rtc_source() == ""
     host_ctx.scene_from_nodes(nodes[:8], list(range(8)), 2)
-    assert host_ctx.rtc_source().count("leaf_sphere(") == 8
+    assert host_ctx.rtc_source().count("leaf_sphere(") >= 8
+    # plain primitive lists: as code only while their BVH is (at most eight leaves); beyond, the data-driven kernels serve
+    prims = [(1, R.make_transform(0.3 * (k % 5) - 0.6, 0.3 * (k // 5) - 0.6, 0.0), [0.1, 0.1, 0.1]) for k in range(30)]
+    host_ctx.scene_from_prims(prims, 2)
+    assert host_ctx.rtc_source() == ""
+    host_ctx.scene_from_prims(prims[:3], 2)
+    assert host_ctx.rtc_source().count("leaf_box(") >= 3
 
 
 @pytest.mark.parametrize("preset,accel,other,scratch_free", [(17, 2, False, True), (17, 1, True, True), (18, 0, False, True), (11, 2, True, True),

@@ -144,7 +144,8 @@ struct rm_ctx {
     int64_t opt_rtc_spheres = 16;
     int64_t opt_prune = 1;  // specialised kernels: exact pruning of smooth unions / subtractions (rm_rtc.cpp); takes effect at the next scene build
     std::string rtc_src;
-    std::map<int, rmrtc::Kernel> rtc_kernels;
+    std::map<int, rmrtc::Kernel> rtc_kernels;   // handles; the modules belong to rm_rtc's process-wide cache ...
+    std::vector<rmrtc::Kernel> rtc_owned;       // ... except these (compiled while the cache was full)
     std::map<int, std::string> rtc_failed;
     std::string rtc_log;  // of the most recent compile
     // small host tables the sharded entry points need on the device (stripe lists, stripe -> source maps): cached by
@@ -188,10 +189,12 @@ const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
     if (it != ctx->rtc_kernels.end()) return &it->second;
     if (ctx->rtc_failed.count(key)) return nullptr;
     rmrtc::Kernel k;
-    if (!rmrtc::compile(ctx->rtc_src, accel, other, ctx->opt_length != 0, true, false, k, ctx->rtc_log)) {
+    bool cached = false;
+    if (!rmrtc::compile_cached(ctx->device, ctx->rtc_src, accel, other, ctx->opt_length != 0, k, ctx->rtc_log, &cached)) {
         ctx->rtc_failed[key] = ctx->rtc_log;
         return nullptr;
     }
+    if (!cached) ctx->rtc_owned.push_back(k);  // the process-wide cache is full: this context unloads the module with the scene
     return &(ctx->rtc_kernels[key] = k);
 }
 
@@ -338,7 +341,8 @@ hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t st
     } while (0)
 
 void free_device_scene(rm_ctx *ctx) {
-    for (auto &kv : ctx->rtc_kernels) rmrtc::release(kv.second);  // (callers have synchronised the device)
+    for (auto &k : ctx->rtc_owned) rmrtc::release(k);  // (callers have synchronised the device)
+    ctx->rtc_owned.clear();
     ctx->rtc_kernels.clear();
     ctx->rtc_failed.clear();
     ctx->last_kernel = "";

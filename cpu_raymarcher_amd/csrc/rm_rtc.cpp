@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 
 // The device sources this library was built from, as the assembler found them at build time (csrc/Makefile runs in this
@@ -562,6 +563,26 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
     out.module = mod;
     out.render = fr;
     out.distance = fd;
+    return true;
+}
+
+bool compile_cached(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log, bool *cached) {
+    static std::mutex mu;
+    static std::map<std::string, Kernel> cache;
+    const char *env = std::getenv("RM_RTC_DEFINES");
+    const std::string key = std::to_string(device) + "|" + std::to_string(accel) + (other ? "|o" : "|s") + (length_sqrt ? "|q|" : "|h|") + (env ? env : "") + "|" + scene_src;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        out = it->second;
+        out.compile_seconds = 0;
+        if (cached) *cached = true;
+        return true;
+    }
+    if (!compile(scene_src, accel, other, length_sqrt, true, false, out, log)) return false;
+    const bool keep = cache.size() < static_cast<size_t>(kCacheEntries);
+    if (keep) cache.emplace(key, out);
+    if (cached) *cached = keep;
     return true;
 }
 

@@ -45,4 +45,11 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
              std::string &log);
 void release(Kernel &k);
 
+// compile(..., load_module = true) through a process-wide cache keyed by (device, source text, accel, other, length): a host
+// that switches back to a scene it has rendered before (the reference's preset menu) gets the loaded module back instead of
+// another 1.5 - 8 s compile.  Cached modules stay loaded for the life of the process (at most kCacheEntries; beyond that
+// kernels are compiled per use and released with their scene: *cached tells which).
+constexpr int kCacheEntries = 256;
+bool compile_cached(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log, bool *cached);
+
 }  // namespace rmrtc

@@ -333,7 +333,8 @@ RM_API int rm_debug_read_stamps(rm_ctx *ctx, uint64_t *out8);
  * by virtual dispatch (src/util/primitives/primitive.ts:33-39 and the overrides in src/util/primitive_operations/ *.ts); here the
  * active scene's trees are emitted as straight-line HIP and compiled for gfx950 with hiprtc into the one-ray-per-lane kernels,
  * once per (acceleration structure, marcher family) the scene is rendered with, at the first such render (1.5 - 3 s,
- * synchronous).  Without libhiprtc.so, for forests above 32 objects / 512 instructions, or with `specialise` = 0 the device
+ * synchronous); loaded kernels are cached for the life of the process (up to 256, keyed by the generated source), so a scene
+ * that comes back -- a preset menu -- does not compile again.  Without libhiprtc.so, for forests above 32 objects / 512 instructions, or with `specialise` = 0 the device
  * interpreter serves the scene (same results: both call the same formula functions in the same order).
  *   rm_rtc_source         the generated source of the active scene (NUL-terminated, truncated to cap; *needed = full size)
  *   rm_rtc_compile_check  compiles it for (accel, other != 0: the marchers other than the sphere tracer) without loading the

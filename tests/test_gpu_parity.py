@@ -1110,6 +1110,25 @@ def test_random_expression_forests_through_rm_scene_from_nodes(rm, gpu_ctx, orac
             assert (d[k] == wd or (np.isnan(d[k]) and np.isnan(wd))) and c[k] == wc, (trial, k, d[k], wd)
 
 
+def test_scene_kernels_are_cached_across_scene_switches(rm, gpu_ctx):
+    """A preset menu goes back and forth: the second visit of a scene must not compile again (rm_rtc's process-wide cache)."""
+    import time as _t
+    gpu_ctx.set_option("specialise", 1)
+
+    def visit(preset):
+        t0 = _t.perf_counter()
+        got = gpu_render(rm, gpu_ctx, preset, "BVH", 64, 48)
+        assert gpu_ctx.last_kernel().startswith("rm_rtc_render<")
+        return _t.perf_counter() - t0, got
+
+    visit(17)
+    visit(6)
+    again, a = visit(17)
+    _, b = visit(17)
+    assert again < 0.5, "preset 17 took %.2f s on its second visit" % again
+    assert all((x == y).all() for x, y in zip(a, b))
+
+
 def _plain_forest(rng, n_roots, depth, k_range):
     """Spheres, boxes and tori (half of them rotated) under Round / SmoothUnion / SmoothSubtraction only: the trees whose
     specialised code prunes operands by binary32 intervals (csrc/rm_rtc.cpp)."""

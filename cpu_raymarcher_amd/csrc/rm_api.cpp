@@ -190,6 +190,12 @@ const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
     if (ctx->rtc_failed.count(key)) return nullptr;
     rmrtc::Kernel k;
     bool cached = false;
+    if (ctx->opt_specialise == 2) {  // never wait: the ahead-of-time kernels render until the background compile has finished
+        const int st = rmrtc::compile_async(ctx->device, ctx->rtc_src, accel, other, ctx->opt_length != 0, k, ctx->rtc_log);
+        if (st < 0) ctx->rtc_failed[key] = ctx->rtc_log;
+        if (st <= 0) return nullptr;
+        return &(ctx->rtc_kernels[key] = k);
+    }
     if (!rmrtc::compile_cached(ctx->device, ctx->rtc_src, accel, other, ctx->opt_length != 0, k, ctx->rtc_log, &cached)) {
         ctx->rtc_failed[key] = ctx->rtc_log;
         return nullptr;
@@ -1478,7 +1484,8 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
         return RM_OK;
     }
     if (!std::strcmp(key, "specialise")) {
-        ctx->opt_specialise = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, RM_E_INVALID, "specialise must be 0, 1 or 2");
+        ctx->opt_specialise = value;
         return RM_OK;
     }
     if (!std::strcmp(key, "lds_fill")) {

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 // The device sources this library was built from, as the assembler found them at build time (csrc/Makefile runs in this
 // directory and lists them as prerequisites of this object).
@@ -566,24 +567,77 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
     return true;
 }
 
-bool compile_cached(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log, bool *cached) {
-    static std::mutex mu;
-    static std::map<std::string, Kernel> cache;
+namespace {
+// (never destroyed: a background compile may outlive static destruction at process exit)
+struct Cache {
+    std::mutex mu;
+    std::map<std::string, Kernel> done;
+    std::map<std::string, std::string> failed;  // key -> log
+    std::map<std::string, bool> running;
+};
+Cache &cache() {
+    static Cache *c = new Cache();
+    return *c;
+}
+std::string cache_key(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt) {
     const char *env = std::getenv("RM_RTC_DEFINES");
-    const std::string key = std::to_string(device) + "|" + std::to_string(accel) + (other ? "|o" : "|s") + (length_sqrt ? "|q|" : "|h|") + (env ? env : "") + "|" + scene_src;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) {
+    return std::to_string(device) + "|" + std::to_string(accel) + (other ? "|o" : "|s") + (length_sqrt ? "|q|" : "|h|") + (env ? env : "") + "|" + scene_src;
+}
+}  // namespace
+
+bool compile_cached(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log, bool *cached) {
+    Cache &c = cache();
+    const std::string key = cache_key(device, scene_src, accel, other, length_sqrt);
+    std::lock_guard<std::mutex> lock(c.mu);  // (a compile in the background of the same key finishes first: it holds no lock while compiling,
+                                             //  so this call may compile a second copy; the first one stored wins)
+    auto it = c.done.find(key);
+    if (it != c.done.end()) {
         out = it->second;
         out.compile_seconds = 0;
         if (cached) *cached = true;
         return true;
     }
     if (!compile(scene_src, accel, other, length_sqrt, true, false, out, log)) return false;
-    const bool keep = cache.size() < static_cast<size_t>(kCacheEntries);
-    if (keep) cache.emplace(key, out);
+    const bool keep = c.done.size() < static_cast<size_t>(kCacheEntries);
+    if (keep) c.done.emplace(key, out);
     if (cached) *cached = keep;
     return true;
+}
+
+int compile_async(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log) {
+    Cache &c = cache();
+    const std::string key = cache_key(device, scene_src, accel, other, length_sqrt);
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.done.find(key);
+        if (it != c.done.end()) {
+            out = it->second;
+            out.compile_seconds = 0;
+            return 1;
+        }
+        auto f = c.failed.find(key);
+        if (f != c.failed.end()) {
+            log = f->second;
+            return -1;
+        }
+        if (c.running.count(key)) return 0;
+        if (c.done.size() >= static_cast<size_t>(kCacheEntries)) {
+            log = "the kernel cache is full";
+            return -1;
+        }
+        c.running[key] = true;
+    }
+    std::thread([key, device, scene_src, accel, other, length_sqrt] {
+        Kernel k;
+        std::string text;
+        const bool ok = hipSetDevice(device) == hipSuccess && compile(scene_src, accel, other, length_sqrt, true, false, k, text);
+        Cache &cc = cache();
+        std::lock_guard<std::mutex> lock(cc.mu);
+        if (ok && !cc.done.count(key)) cc.done.emplace(key, k);
+        else if (!ok) cc.failed[key] = text;
+        cc.running.erase(key);
+    }).detach();
+    return 0;
 }
 
 void release(Kernel &k) {

@@ -51,5 +51,9 @@ void release(Kernel &k);
 // kernels are compiled per use and released with their scene: *cached tells which).
 constexpr int kCacheEntries = 256;
 bool compile_cached(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log, bool *cached);
+// The same without waiting: 1 = the kernel is in the cache (out is set), 0 = a background thread is compiling it (started by
+// this call or an earlier one; the caller renders with its ahead-of-time kernels meanwhile -- same bytes), -1 = that compile
+// failed or the cache is full (log says which).
+int compile_async(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log);
 
 }  // namespace rmrtc

@@ -382,8 +382,10 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *   lds_fill 0|1  v2: pad the LDS request so that exactly blocks_per_cu workgroups fit a CU (default 0; measurement knob)
  *   item_wide 0|1 v2: the 64-pixel batches of a work item side by side (item = tile_w * item_px / 64 pixels wide) instead of one
  *                 above the other (default 0: measured no gain in write traffic, 2 % slower with frames in flight)
- *   specialise 0|1  expression forests: 1 (default) = the scene's trees compiled into the kernel at run time (rm_rtc_* above),
- *                 0 = the device interpreter of csrc/rm_program.h
+ *   specialise 0|1|2  small scenes: 1 (default) = the scene compiled into the kernel at run time (rm_rtc_* above), waiting for the
+ *                 compile at the first render; 2 = the same without waiting -- a background thread compiles, the ahead-of-time
+ *                 kernels render meanwhile (same bytes), the scene's own kernel takes over when it is ready; 0 = the
+ *                 ahead-of-time kernels only (the device interpreter of csrc/rm_program.h for operator trees)
  *   rtc_spheres 0..33  sphere lists of fewer spheres than this (default 16) and primitive lists of up to 32 primitives are compiled
  *                 too, one single-leaf object per primitive, when their BVH has at most eight leaves (emitted as code: no node
  *                 walks in memory); they then run in the one-ray-per-lane kernel instead of the v2 wave loop

@@ -1129,6 +1129,39 @@ def test_scene_kernels_are_cached_across_scene_switches(rm, gpu_ctx):
     assert all((x == y).all() for x, y in zip(a, b))
 
 
+def test_background_compile_never_waits_and_takes_over(rm, gpu_ctx, oracle):
+    """`specialise` = 2: the first renders of a new scene run in the ahead-of-time kernel while a background thread compiles; the
+    scene's own kernel takes over when it is ready; every frame equals the oracle's."""
+    import time as _t
+    rng = np.random.default_rng(77)  # a forest no other test builds: not in the process-wide cache
+    forest = _plain_forest(rng, 2, 3, (3e-4, 7e-3))
+    osc = oracle.OracleScene(accel="BVH", prims=forest)
+    osc.set_angles(0.1, 0.4)
+    want = osc.render(160, 100)
+    gpu_ctx.set_option("specialise", 2)
+    try:
+        t0 = _t.perf_counter()
+        got = gpu_render(rm, gpu_ctx, None, "BVH", 160, 100, (0.1, 0.4), nodes=osc.nodes())
+        first = _t.perf_counter() - t0
+        assert gpu_ctx.last_kernel().startswith("render_kernel<"), gpu_ctx.last_kernel()
+        assert_same(got, want, "while the scene's kernel compiles")
+        assert first < 1.0, "the first render waited %.2f s" % first
+        sc = rm.Scene("BVH", ctx=gpu_ctx)
+        sc.loadNodes(*osc.nodes())
+        sc.camera.setAngles(0.1, 0.4)
+        deadline = _t.perf_counter() + 60
+        while _t.perf_counter() < deadline:
+            bufs = (np.zeros(16000, np.uint8), np.zeros(48000, np.uint8), np.zeros(16000, np.uint16), np.zeros(16000, np.uint16))
+            rm.createRaymarcher("sphere-tracer", None, None).runRaymarcher(sc, *bufs, 160, 100, 0.0, 0, 100)
+            if gpu_ctx.last_kernel().startswith("rm_rtc_render<"):
+                break
+            _t.sleep(0.2)
+        assert gpu_ctx.last_kernel().startswith("rm_rtc_render<"), gpu_ctx.rtc_status()
+        assert_same(bufs, want, "after the take-over")
+    finally:
+        gpu_ctx.set_option("specialise", 1)
+
+
 def _plain_forest(rng, n_roots, depth, k_range):
     """Spheres, boxes and tori (half of them rotated) under Round / SmoothUnion / SmoothSubtraction only: the trees whose
     specialised code prunes operands by binary32 intervals (csrc/rm_rtc.cpp)."""

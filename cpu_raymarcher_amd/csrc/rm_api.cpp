@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <unordered_map>
 #include <new>
 #include <string>
 #include <vector>
@@ -148,6 +149,18 @@ struct rm_ctx {
     std::vector<rmrtc::Kernel> rtc_owned;       // ... except these (compiled while the cache was full)
     std::map<int, std::string> rtc_failed;
     std::string rtc_log;  // of the most recent compile
+    // The v2 wave loop compiled for a launch configuration that keeps coming back (rm_v2_fields.h, rm_rtc_v2_hook below): after
+    // `specialise_v2_after` launches with the same configuration (default 3; 0: never) the kernel is compiled with that
+    // configuration's parameters as literals (~2 s; synchronous with `specialise` = 1, in the background with 2) and used from
+    // then on.  Keyed by a hash of the configuration; the modules live in rm_rtc's process-wide cache.
+    struct V2Special {
+        int launches = 0;
+        int state = 0;  // 0 counting, 2 compiling in the background, 1 ready, -1 failed
+        bool lite = false;  // the first compile (with the scene's counts as literals) was refused: without them
+        rmrtc::Kernel k;
+    };
+    std::unordered_map<uint64_t, V2Special> v2_special;
+    int64_t opt_v2_after = 3;
     // small host tables the sharded entry points need on the device (stripe lists, stripe -> source maps): cached by
     // content, each in its own allocation, so a table a launch in flight still reads is never overwritten
     struct DevTable {
@@ -204,8 +217,44 @@ const rmrtc::Kernel *specialised_kernel(rm_ctx *ctx, int accel, bool other) {
     return &(ctx->rtc_kernels[key] = k);
 }
 
+}  // namespace
+
+const void *rm_rtc_v2_hook(const RmRenderParams &p, int accel, bool lds, bool ur, bool rel, bool length_sqrt) {
+    rm_ctx *ctx = static_cast<rm_ctx *>(p.rtc_ctx);
+    if (!ctx || !ctx->opt_specialise || ctx->opt_v2_after <= 0) return nullptr;
+    const int bits = (accel & 3) | (lds ? 4 : 0) | (ur ? 8 : 0) | (rel ? 16 : 0) | rmrtc::kV2Bit;
+    rm_ctx::V2Special &e = ctx->v2_special[rmrtc::v2_fixed_hash(p, bits | (length_sqrt ? 512 : 0))];
+    if (e.state == 1) return e.k.render;
+    if (e.state < 0) return nullptr;
+    if (e.state == 0 && ++e.launches < ctx->opt_v2_after) return nullptr;
+    // with the scene's counts as literals first; a kernel refused for spilling (small scenes: their loops unroll) once more without
+    for (;;) {
+        const std::string src = rmrtc::v2_fixed_source(p, !e.lite);
+        bool failed = false;
+        if (ctx->opt_specialise == 2) {
+            const int st = rmrtc::compile_async(ctx->device, src, bits, false, length_sqrt, e.k, ctx->rtc_log);
+            e.state = st > 0 ? 1 : (st < 0 ? -1 : 2);
+            failed = st < 0;
+        } else {
+            bool cached = false;
+            failed = !rmrtc::compile_cached(ctx->device, src, bits, false, length_sqrt, e.k, ctx->rtc_log, &cached);
+            e.state = failed ? -1 : 1;
+            if (!failed && !cached) ctx->rtc_owned.push_back(e.k);
+        }
+        if (!failed || e.lite) break;
+        e.lite = true;
+        e.state = 0;
+    }
+    return e.state == 1 ? e.k.render : nullptr;
+}
+
+namespace {
+
 hipError_t launch_render(rm_ctx *ctx, const RmRenderParams &p_in, hipStream_t stream) {
     RmRenderParams p = p_in;
+#if !defined(RM_STAMPS) && !defined(RM_COUNTS) && !defined(RM_STAMPS_LOG) && !defined(RM_STAMPS_CLAIM)  // (diagnostic builds keep their instrumented kernels)
+    p.rtc_ctx = ctx;
+#endif
     // every launch of the one-ray-per-lane kernels (not the v2 wave loop, not the lean octree kernel) takes the scene's own kernel if it has one
     const bool lean_oct = p.accel == 1 && p.oct_lean && !p.general && p.algorithm == 0 && p.oct_lut && p.oct_recs && p.filter;
     const rmrtc::Kernel *special = (p.variant == 2 && p.algorithm == 0) || lean_oct ? nullptr : specialised_kernel(ctx, p.accel, p.algorithm != 0);
@@ -350,6 +399,7 @@ void free_device_scene(rm_ctx *ctx) {
     for (auto &k : ctx->rtc_owned) rmrtc::release(k);  // (callers have synchronised the device)
     ctx->rtc_owned.clear();
     ctx->rtc_kernels.clear();
+    ctx->v2_special.clear();  // (a new scene is a new configuration anyway: its counts and LDS layout are in the key)
     ctx->rtc_failed.clear();
     ctx->last_kernel = "";
     if (!ctx->has_device) return;
@@ -1389,8 +1439,13 @@ int rm_rtc_compile_check(rm_ctx *ctx, int32_t accel, int32_t other, char *log, i
 
 int rm_rtc_status(rm_ctx *ctx, int32_t *compiled, int32_t *failed, char *log, int64_t cap) {
     if (!ctx) return RM_E_INVALID;
-    if (compiled) *compiled = static_cast<int32_t>(ctx->rtc_kernels.size());
-    if (failed) *failed = static_cast<int32_t>(ctx->rtc_failed.size());
+    int v2_ready = 0, v2_failed = 0;
+    for (const auto &kv : ctx->v2_special) {
+        v2_ready += kv.second.state == 1;
+        v2_failed += kv.second.state < 0;
+    }
+    if (compiled) *compiled = static_cast<int32_t>(ctx->rtc_kernels.size()) + v2_ready;
+    if (failed) *failed = static_cast<int32_t>(ctx->rtc_failed.size()) + v2_failed;
     std::string why;
     if (!rmrtc::available(&why)) return copy_text(why, log, cap, nullptr);
     return copy_text(ctx->rtc_log, log, cap, nullptr);
@@ -1481,6 +1536,11 @@ int rm_set_option(rm_ctx *ctx, const char *key, int64_t value) {
     if (!std::strcmp(key, "rtc_spheres")) {
         if (value < 0 || value > 33) return fail(ctx, RM_E_INVALID, "rtc_spheres must be 0..33");
         ctx->opt_rtc_spheres = value;
+        return RM_OK;
+    }
+    if (!std::strcmp(key, "specialise_v2_after")) {
+        if (value < 0 || value > 1000000) return fail(ctx, RM_E_INVALID, "specialise_v2_after must be 0 (never) .. 1000000 launches");
+        ctx->opt_v2_after = value;
         return RM_OK;
     }
     if (!std::strcmp(key, "specialise")) {
@@ -1592,6 +1652,7 @@ int rm_get_option(const rm_ctx *ctx, const char *key, int64_t *value) {
     else if (!std::strcmp(key, "lds_kb")) *value = ctx->opt_lds_kb;
     else if (!std::strcmp(key, "lds_fill")) *value = ctx->opt_lds_fill;
     else if (!std::strcmp(key, "specialise")) *value = ctx->opt_specialise;
+    else if (!std::strcmp(key, "specialise_v2_after")) *value = ctx->opt_v2_after;
     else if (!std::strcmp(key, "rtc_spheres")) *value = ctx->opt_rtc_spheres;
     else if (!std::strcmp(key, "prune")) *value = ctx->opt_prune;
     else if (!std::strcmp(key, "item_wide")) *value = ctx->opt_item_wide;

@@ -21,9 +21,11 @@ struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
 #ifdef RM_LENGTH_SQRT
 #define RM_LEN_VARIANT(name) name##_sqrt
 #define RM_LEN_TAG " [length=sqrt]"
+#define RM_LEN_IS_SQRT true
 #else
 #define RM_LEN_VARIANT(name) name
 #define RM_LEN_TAG ""
+#define RM_LEN_IS_SQRT false
 #endif
 
 #ifndef __HIPCC_RTC__  // (host side: the launchers)
@@ -31,6 +33,11 @@ struct RmDiagDevice {  // accumulator of rm_reduce_counters_device (32 bytes)
 // instantiation that was launched (static string).
 hipError_t rm_launch_render(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
 hipError_t rm_launch_render_sqrt(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);
+
+// Asked by rm_launch_render_v2 for every launch that carries a context (RmRenderParams::rtc_ctx): the hipFunction_t of the
+// wave loop compiled for this launch's configuration (rm_v2_fields.h), or null -- the library's own instantiation runs.
+// Implemented in rm_api.cpp (it counts how often a configuration comes back and owns the compile policy).
+const void *rm_rtc_v2_hook(const RmRenderParams &p, int accel, bool lds, bool ur, bool rel, bool length_sqrt);
 
 // v2 kernel (rm_render_v2.hip); called by rm_launch_render when p.variant == 2
 hipError_t rm_launch_render_v2(const RmRenderParams &p, hipStream_t stream, const char **kernel_name);

@@ -24,9 +24,14 @@
 //  * XCD-aware tile order: workgroups b, b+8, b+16 ... share an XCD (round-robin dispatch);
 //    they are given horizontally adjacent tiles of one tile row so the partial-line stores of
 //    neighbouring tiles merge in that XCD's L2 before they reach HBM.
+#ifndef __HIPCC_RTC__  // (hiprtc brings its own runtime declarations: rm_rtc.cpp compiles this file too, see RM_RTC_V2 below)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rm_device.h"
+#ifdef RM_RTC_V2  // the run-time specialiser's build: this launch configuration's parameters as literals (rm_v2_fields.h)
+#include "rm_v2_fixed.inc"
+#endif
 
 // Diagnostic build only (-DRM_COUNTS): how often each part of the wave loop executes -- per event the number of
 // wave-level executions (slot i) and the number of lanes active in them (slot i + 16), accumulated in LDS and added
@@ -912,7 +917,13 @@ __device__ __forceinline__ RmRenderParams cold_params() {
     typedef const __attribute__((address_space(4))) RmRenderParams *KernArgs;
     KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();  // P is the kernel's only argument
     asm volatile("" : "+s"(p));
+#ifdef RM_RTC_V2  // what is configuration is a literal (rm_v2_fix, generated); what is left -- pointers, camera, rows -- is loaded
+    RmRenderParams r = *p;
+    rm_v2_fix(r);
+    return r;
+#else
     return *p;
+#endif
 #else
     return RmRenderParams();
 #endif
@@ -924,7 +935,10 @@ template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
 // builds spilled at five and ran at four); what changed is the lane state (see "lane state" below), the wave index as an
 // SGPR, and -amdgpu-inline-max-bb (Makefile).
 #define RM_V2_WAVES 6
-__global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRenderParams P) {
+__device__ __forceinline__ void render_v2_body(const RmRenderParams &P) {
+    // (RM_RTC_V2 builds: the literals are applied where the wave loop re-loads the block, cold_params; what runs once per
+    // workgroup here reads the kernel argument as it is -- a patched local copy of the block indexed at run time, as the REL
+    // staging loop does, would live in scratch)
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ WaveDiag wave_diag[4];
     const int lane0 = threadIdx.x & 63;  // (used before the wave loop only: inside it the lane id is re-derived where needed, see lane_now)
@@ -1478,6 +1492,17 @@ __global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRen
 #endif
 }
 
+#ifdef RM_RTC_V2
+}  // namespace
+extern "C" __global__ __launch_bounds__(256, RM_V2_WAVES) void rm_rtc_render_v2(const RmRenderParams P) {
+    render_v2_body<RM_RTC_V2_ACCEL, RM_RTC_V2_LDS != 0, RM_RTC_V2_UR != 0, RM_RTC_V2_REL != 0>(P);
+}
+#else
+template <int ACCEL, bool LDS, bool UR = false, bool REL = false>
+__global__ __launch_bounds__(256, RM_V2_WAVES) void render_kernel_v2(const RmRenderParams P) {
+    render_v2_body<ACCEL, LDS, UR, REL>(P);
+}
+
 size_t scene_lds_bytes(const RmRenderParams &p) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t b = 0;
@@ -1665,10 +1690,22 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
         p.lpt_cost_out = nullptr;
     }
     const dim3 grid(blocks), block(256);
-#define RM_V2X(A, L, U, R)                                                                                  \
-    {                                                                                                       \
-        hipLaunchKernelGGL((render_kernel_v2<A, L, U, R>), grid, block, shmem, stream, p);                  \
-        if (kernel_name) *kernel_name = "render_kernel_v2<" #A ", " #L ", " #U ", " #R ">" RM_LEN_TAG;      \
+    // A launch configuration that keeps coming back runs in a copy of this kernel compiled for it, its configuration
+    // parameters literals (rm_v2_fields.h; rm_api.cpp decides when, rm_rtc.cpp compiles): same grid, same LDS, same bytes.
+#define RM_V2X(A, L, U, R)                                                                                                   \
+    {                                                                                                                        \
+        const void *fn_ = p.rtc_ctx ? rm_rtc_v2_hook(p, A, L, U, R, RM_LEN_IS_SQRT) : nullptr;                               \
+        if (fn_) {                                                                                                           \
+            size_t bytes_ = sizeof p;                                                                                        \
+            void *extra_[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes_, HIP_LAUNCH_PARAM_END}; \
+            e = hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(const_cast<void *>(fn_)), grid.x, 1, 1, 256, 1, 1,     \
+                                      static_cast<unsigned>(shmem), stream, nullptr, extra_);                               \
+            if (e != hipSuccess) return e;                                                                                   \
+            if (kernel_name) *kernel_name = "render_kernel_v2<" #A ", " #L ", " #U ", " #R ">" RM_LEN_TAG " [launch constants compiled in]"; \
+        } else {                                                                                                             \
+            hipLaunchKernelGGL((render_kernel_v2<A, L, U, R>), grid, block, shmem, stream, p);                               \
+            if (kernel_name) *kernel_name = "render_kernel_v2<" #A ", " #L ", " #U ", " #R ">" RM_LEN_TAG;                   \
+        }                                                                                                                    \
     }
 #define RM_V2(A, L) RM_V2X(A, L, false, false)
     if (p.accel == 2) {
@@ -1684,3 +1721,4 @@ hipError_t RM_LEN_VARIANT(rm_launch_render_v2)(const RmRenderParams &p_in, hipSt
 #undef RM_V2
     return hipGetLastError();
 }
+#endif  // !RM_RTC_V2

@@ -1,6 +1,8 @@
 // rm_rtc.cpp -- see rm_rtc.h.  Host only.
 #include "rm_rtc.h"
 
+#include "rm_v2_fields.h"
+
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
@@ -21,6 +23,7 @@
     __asm__(".pushsection .rodata\n .hidden " #sym "\n .global " #sym "\n" #sym ":\n .incbin \"" file "\"\n .byte 0\n .popsection\n"); \
     extern "C" const char sym[];
 RM_EMBED(rm_src_kernels_hip, "rm_kernels.hip")
+RM_EMBED(rm_src_render_v2_hip, "rm_render_v2.hip")
 RM_EMBED(rm_src_device_h, "rm_device.h")
 RM_EMBED(rm_src_jsmath_h, "rm_jsmath.h")
 RM_EMBED(rm_src_types_h, "rm_types.h")
@@ -490,15 +493,35 @@ bool available(std::string *why) {
     return r.lib != nullptr;
 }
 
-bool compile(const std::string &scene_src, int accel, bool other, bool length_sqrt, bool load_module, bool want_remarks, Kernel &out,
-             std::string &log) {
+namespace {
+
+// one hiprtc compile of one embedded source file around one generated header
+struct Unit {
+    std::string defines;      // #define lines ahead of the #include of `main_file`
+    const char *main_file;    // "rm_kernels.hip" | "rm_render_v2.hip"
+    const char *gen_name;     // the generated header's name
+    const std::string *gen;   // ... and text
+    const char *render_fn;    // kernel to look up (out.render)
+    const char *distance_fn;  // second kernel (out.distance) or null
+    std::string display;      // what rm_last_kernel reports
+    bool no_spills;           // refuse a kernel that spills VGPRs or uses scratch (the v2 wave loop: the ahead-of-time build holds that line, and
+                              // hipcc 7.2 can place a spill ahead of an EXEC restore: profiles/r03/spill_exec_hazard.txt)
+};
+
+// the value behind "<key>: N" of the resource-usage remarks of function `fn` (-1: not found)
+long remark_of(const std::string &log, const char *fn, const char *key) {
+    size_t at = log.find(std::string("Function Name: ") + fn);
+    if (at == std::string::npos) return -1;
+    const size_t next = log.find("Function Name: ", at + 15);
+    at = log.find(std::string(key) + ": ", at);
+    if (at == std::string::npos || (next != std::string::npos && at > next)) return -1;
+    return std::strtol(log.c_str() + at + std::strlen(key) + 2, nullptr, 10);
+}
+
+bool compile_unit(const Unit &u, bool load_module, bool want_remarks, Kernel &out, std::string &log) {
     Rtc &r = rtc();
     if (!r.lib) {
         log = r.why;
-        return false;
-    }
-    if (scene_src.empty()) {
-        log = "no specialised source for this scene";
         return false;
     }
     // RM_RTC_DEFINES (environment; experiments only): names to #define ahead of the sources, separated by blanks
@@ -514,20 +537,19 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
             }
         }
     }
-    const std::string main_src = extra + "#define RM_RTC 1\n#define RM_RTC_ACCEL " + std::to_string(accel == 1 || accel == 2 ? accel : 0) + "\n#define RM_RTC_OTHER " +
-                                 (other ? "1" : "0") + "\n" + (length_sqrt ? "#define RM_LENGTH_SQRT 1\n" : "") + "#include \"rm_kernels.hip\"\n";
-    const char *names[] = {"rm_kernels.hip", "rm_device.h", "rm_jsmath.h", "rm_types.h", "rm_program.h", "rm_bvh_list.h", "rm_kernels.h", "rm_diag.h",
-                           "rm_rtc_scene.inc"};
-    const char *texts[] = {rm_src_kernels_hip, rm_src_device_h, rm_src_jsmath_h, rm_src_types_h, rm_src_program_h, rm_src_bvh_list_h, rm_src_kernels_h,
-                           rm_src_diag_h, scene_src.c_str()};
+    const std::string main_src = extra + u.defines + "#include \"" + u.main_file + "\"\n";
+    const char *names[] = {"rm_kernels.hip", "rm_render_v2.hip", "rm_device.h", "rm_jsmath.h", "rm_types.h", "rm_program.h", "rm_bvh_list.h", "rm_kernels.h",
+                           "rm_diag.h", u.gen_name};
+    const char *texts[] = {rm_src_kernels_hip, rm_src_render_v2_hip, rm_src_device_h, rm_src_jsmath_h, rm_src_types_h, rm_src_program_h, rm_src_bvh_list_h,
+                           rm_src_kernels_h, rm_src_diag_h, u.gen->c_str()};
     hiprtcProgram prog = nullptr;
-    if (r.create(&prog, main_src.c_str(), "rm_rtc_main.hip", 9, texts, names) != HIPRTC_SUCCESS) {
+    if (r.create(&prog, main_src.c_str(), "rm_rtc_main.hip", 10, texts, names) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return false;
     }
     // the flags of csrc/Makefile
     std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-inline-max-bb=100000"};
-    if (want_remarks) opts.push_back("-Rpass-analysis=kernel-resource-usage");
+    if (want_remarks || u.no_spills) opts.push_back("-Rpass-analysis=kernel-resource-usage");
     const auto t0 = std::chrono::steady_clock::now();
     const hiprtcResult res = r.compile(prog, static_cast<int>(opts.size()), opts.data());
     out.compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -541,12 +563,20 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
         if (log.empty()) log = "hiprtcCompileProgram failed";
         return false;
     }
+    if (u.no_spills) {
+        const long spills = remark_of(log, u.render_fn, "VGPRs Spill"), scratch = remark_of(log, u.render_fn, "ScratchSize [bytes/lane]");
+        if (spills != 0 || scratch != 0) {
+            r.destroy(&prog);
+            log = "refused: " + std::string(u.render_fn) + " spills " + std::to_string(spills) + " VGPRs, " + std::to_string(scratch) + " bytes of scratch per lane\n" + log;
+            return false;
+        }
+    }
     size_t cs = 0;
     r.code_size(prog, &cs);
     std::vector<char> code(cs);
     r.code(prog, code.data());
     r.destroy(&prog);
-    out.name = std::string("rm_rtc_render<") + std::to_string(accel) + ", " + (other ? "true" : "false") + ">" + (length_sqrt ? " [length=sqrt]" : "");
+    out.name = u.display;
     if (!load_module) return true;
     hipModule_t mod = nullptr;
     hipFunction_t fr = nullptr, fd = nullptr;
@@ -555,8 +585,8 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
         (void)hipGetLastError();
         return false;
     }
-    if (hipModuleGetFunction(&fr, mod, "rm_rtc_render") != hipSuccess || hipModuleGetFunction(&fd, mod, "rm_rtc_distance") != hipSuccess) {
-        log += "\nthe compiled module lacks rm_rtc_render / rm_rtc_distance";
+    if (hipModuleGetFunction(&fr, mod, u.render_fn) != hipSuccess || (u.distance_fn && hipModuleGetFunction(&fd, mod, u.distance_fn) != hipSuccess)) {
+        log += "\nthe compiled module lacks its kernels";
         (void)hipGetLastError();
         (void)hipModuleUnload(mod);
         return false;
@@ -565,6 +595,83 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
     out.render = fr;
     out.distance = fd;
     return true;
+}
+
+template <typename T>
+std::string lit_of(T v) { return std::to_string(v); }
+template <>
+std::string lit_of<uint32_t>(uint32_t v) { return std::to_string(v) + "u"; }
+template <>
+std::string lit_of<float>(float v) { return lit_f(v); }
+template <>
+std::string lit_of<double>(double v) { return lit_d(v); }
+
+}  // namespace
+
+bool compile(const std::string &scene_src, int accel, bool other, bool length_sqrt, bool load_module, bool want_remarks, Kernel &out,
+             std::string &log) {
+    if (scene_src.empty()) {
+        log = "no specialised source for this scene";
+        return false;
+    }
+    Unit u;
+    u.defines = "#define RM_RTC 1\n#define RM_RTC_ACCEL " + std::to_string(accel == 1 || accel == 2 ? accel : 0) + "\n#define RM_RTC_OTHER " + (other ? "1" : "0") + "\n" +
+                (length_sqrt ? "#define RM_LENGTH_SQRT 1\n" : "");
+    u.main_file = "rm_kernels.hip";
+    u.gen_name = "rm_rtc_scene.inc";
+    u.gen = &scene_src;
+    u.render_fn = "rm_rtc_render";
+    u.distance_fn = "rm_rtc_distance";
+    u.display = std::string("rm_rtc_render<") + std::to_string(accel) + ", " + (other ? "true" : "false") + ">" + (length_sqrt ? " [length=sqrt]" : "");
+    u.no_spills = false;
+    return compile_unit(u, load_module, want_remarks, out, log);
+}
+
+// ---- the v2 wave loop with a launch configuration's parameters as literals (rm_v2_fields.h) -------------------------------------
+std::string v2_fixed_source(const RmRenderParams &p, bool with_counts) {
+    std::string s = "// generated by rm_rtc.cpp: the configuration parameters of one launch of the v2 wave loop (rm_v2_fields.h)\n"
+                    "__device__ __forceinline__ void rm_v2_fix(RmRenderParams &C) {\n";
+#define RM_X(f) s += "    C." #f " = " + lit_of(p.f) + ";\n";
+    RM_V2_FIXED_SCALARS(RM_X)
+    if (with_counts) {
+        RM_V2_FIXED_COUNTS(RM_X)
+    }
+#undef RM_X
+#define RM_X(f, n) \
+    for (int k = 0; k < n; ++k) s += "    C." #f "[" + std::to_string(k) + "] = " + lit_of(p.f[k]) + ";\n";
+    RM_V2_FIXED_ARRAYS(RM_X)
+#undef RM_X
+    return s + "}\n";
+}
+
+uint64_t v2_fixed_hash(const RmRenderParams &p, int variant_bits) {
+    uint64_t h = 1469598103934665603ull ^ static_cast<uint64_t>(variant_bits);
+    auto mix = [&](const void *d, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(d);
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+#define RM_X(f) mix(&p.f, sizeof p.f);
+    RM_V2_FIXED_SCALARS(RM_X)
+    RM_V2_FIXED_COUNTS(RM_X)
+#undef RM_X
+#define RM_X(f, n) mix(p.f, sizeof p.f);
+    RM_V2_FIXED_ARRAYS(RM_X)
+#undef RM_X
+    return h;
+}
+
+bool compile_v2(const std::string &fixed_src, int accel, bool lds, bool ur, bool rel, bool length_sqrt, bool load_module, Kernel &out, std::string &log) {
+    Unit u;
+    u.defines = "#define RM_RTC_V2 1\n#define RM_RTC_V2_ACCEL " + std::to_string(accel) + "\n#define RM_RTC_V2_LDS " + (lds ? "1" : "0") + "\n#define RM_RTC_V2_UR " +
+                (ur ? "1" : "0") + "\n#define RM_RTC_V2_REL " + (rel ? "1" : "0") + "\n" + (length_sqrt ? "#define RM_LENGTH_SQRT 1\n" : "");
+    u.main_file = "rm_render_v2.hip";
+    u.gen_name = "rm_v2_fixed.inc";
+    u.gen = &fixed_src;
+    u.render_fn = "rm_rtc_render_v2";
+    u.distance_fn = nullptr;
+    u.display = "rm_rtc_render_v2";
+    u.no_spills = true;
+    return compile_unit(u, load_module, false, out, log);
 }
 
 namespace {
@@ -579,9 +686,15 @@ Cache &cache() {
     static Cache *c = new Cache();
     return *c;
 }
+// `accel` carries the instantiation: scene kernels (other = marcher family) the acceleration structure; the v2 wave loop
+// (kV2Bit set) ACCEL | LDS << 2 | UR << 3 | REL << 4
 std::string cache_key(int device, const std::string &scene_src, int accel, bool other, bool length_sqrt) {
     const char *env = std::getenv("RM_RTC_DEFINES");
     return std::to_string(device) + "|" + std::to_string(accel) + (other ? "|o" : "|s") + (length_sqrt ? "|q|" : "|h|") + (env ? env : "") + "|" + scene_src;
+}
+bool compile_any(const std::string &src, int accel, bool other, bool length_sqrt, Kernel &out, std::string &log) {
+    if (accel & kV2Bit) return compile_v2(src, accel & 3, (accel >> 2) & 1, (accel >> 3) & 1, (accel >> 4) & 1, length_sqrt, true, out, log);
+    return compile(src, accel, other, length_sqrt, true, false, out, log);
 }
 }  // namespace
 
@@ -597,7 +710,7 @@ bool compile_cached(int device, const std::string &scene_src, int accel, bool ot
         if (cached) *cached = true;
         return true;
     }
-    if (!compile(scene_src, accel, other, length_sqrt, true, false, out, log)) return false;
+    if (!compile_any(scene_src, accel, other, length_sqrt, out, log)) return false;
     const bool keep = c.done.size() < static_cast<size_t>(kCacheEntries);
     if (keep) c.done.emplace(key, out);
     if (cached) *cached = keep;
@@ -630,7 +743,7 @@ int compile_async(int device, const std::string &scene_src, int accel, bool othe
     std::thread([key, device, scene_src, accel, other, length_sqrt] {
         Kernel k;
         std::string text;
-        const bool ok = hipSetDevice(device) == hipSuccess && compile(scene_src, accel, other, length_sqrt, true, false, k, text);
+        const bool ok = hipSetDevice(device) == hipSuccess && compile_any(scene_src, accel, other, length_sqrt, k, text);
         Cache &cc = cache();
         std::lock_guard<std::mutex> lock(cc.mu);
         if (ok && !cc.done.count(key)) cc.done.emplace(key, k);

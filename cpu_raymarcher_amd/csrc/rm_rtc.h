@@ -45,6 +45,15 @@ bool compile(const std::string &scene_src, int accel, bool other, bool length_sq
              std::string &log);
 void release(Kernel &k);
 
+// The v2 wave loop (rm_render_v2.hip) compiled for ONE launch configuration: rm_v2_fix() assigns every configuration parameter
+// (rm_v2_fields.h) its value as a literal; the kernel applies it to the parameter block wherever it (re)loads it.
+std::string v2_fixed_source(const RmRenderParams &p, bool with_counts);  // with_counts: the scene's counts too (rm_v2_fields.h says when not)
+uint64_t v2_fixed_hash(const RmRenderParams &p, int variant_bits);  // cheap identity of (configuration, instantiation) for the per-launch lookup
+// accel / lds / ur / rel: the instantiation render_kernel_v2<ACCEL, LDS, UR, REL> the launcher chose.  A kernel that spills or
+// uses scratch is refused (log says so).
+bool compile_v2(const std::string &fixed_src, int accel, bool lds, bool ur, bool rel, bool length_sqrt, bool load_module, Kernel &out, std::string &log);
+constexpr int kV2Bit = 1 << 8;  // in the `accel` argument of compile_cached / compile_async: ACCEL | LDS << 2 | UR << 3 | REL << 4 | kV2Bit
+
 // compile(..., load_module = true) through a process-wide cache keyed by (device, source text, accel, other, length): a host
 // that switches back to a scene it has rendered before (the reference's preset menu) gets the loaded module back instead of
 // another 1.5 - 8 s compile.  Cached modules stay loaded for the life of the process (at most kCacheEntries; beyond that

@@ -188,6 +188,7 @@ struct RmRenderParams {
     int32_t item_wide, item_w_log2, sub_dx, sub_dy;
     // Host side only (the launchers): the hipFunction_t of this scene's run-time specialised kernel (rm_rtc.h), or null
     const void *rtc_function;
+    void *rtc_ctx;  // host side only: the context whose policy decides about a run-time compiled copy of the v2 kernel (rm_rtc_v2_hook); null: never
     uint32_t tiles_x_magic;
     int32_t lds_budget_kb;  // v2: LDS budget per workgroup the launcher aims for (option `lds_kb`; 0 = six workgroups per CU, then five, then four)
     int32_t leaf_order;  // BVH leaf lists are consecutive: leaf = spheres[first .. first+count), no id reads

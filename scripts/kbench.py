@@ -128,6 +128,9 @@ def main():
             verdict += " DIAG MISMATCH %s vs %s" % (d, ctx.decode_acc(chk))
         print("%-9s %-16s alone %7.3f ms | %2d in flight %7.1f frames/s (%.3f ms) | avg sdf %.3f it %.3f | %s"
               % (name, verdict, alone, S, fps, 1e3 / fps, d["total_sdf"] / (W * H), d["total_iters"] / (W * H), kern), flush=True)
+        done, bad, log = ctx.rtc_status()
+        if bad:
+            print("   run-time compiles: %d ready, %d FAILED: %s" % (done, bad, log[:1500]), flush=True)
 
 
 if __name__ == "__main__":

@@ -1129,6 +1129,47 @@ def test_scene_kernels_are_cached_across_scene_switches(rm, gpu_ctx):
     assert all((x == y).all() for x, y in zip(a, b))
 
 
+def test_v2_wave_loop_compiled_for_its_configuration(rm, oracle):
+    """The v2 kernel compiled at run time with a launch configuration's parameters as literals (rm_v2_fields.h): same bytes as
+    the library's own instantiation and as the oracle; the camera and the rows of a launch are not part of the configuration
+    (no further compile), the frame size and the shader are."""
+    ctx = rm.Context(0)
+    tag = "[launch constants compiled in]"
+
+    def render(preset, accel, W, H, ang, rows=None, spheres=None):
+        return gpu_render(rm, ctx, preset, accel, W, H, ang, rows=rows, spheres=spheres)
+
+    try:
+        ctx.set_option("specialise_v2_after", 1)
+        compiled0 = ctx.rtc_status()[0]
+        for ang in ((0.0, 0.0), (0.3, 0.7), (-0.4, 2.1)):  # one configuration, three cameras
+            got = render(3, "BVH", 320, 180, ang)
+            assert tag in ctx.last_kernel(), (ctx.last_kernel(), ctx.rtc_status())
+            assert_same(got, cpu_render(oracle, 3, "BVH", 320, 180, ang), "compiled v2, camera %s" % (ang,))
+        assert ctx.rtc_status()[0] == compiled0 + 1, ctx.rtc_status()
+        got = render(3, "BVH", 320, 180, (0.3, 0.7), rows=(40, 100))  # a band of rows: the same configuration
+        assert tag in ctx.last_kernel() and ctx.rtc_status()[0] == compiled0 + 1
+        assert_same(got, cpu_render(oracle, 3, "BVH", 320, 180, (0.3, 0.7), rows=(40, 100)), "compiled v2, a band of rows")
+        got = render(3, "None", 200, 120, (0.2, 0.5))  # another configuration (no acceleration, another frame size)
+        assert tag in ctx.last_kernel() and ctx.rtc_status()[:2] == (1, 0), ctx.rtc_status()  # (a new scene build starts the context's list afresh)
+        assert_same(got, cpu_render(oracle, 3, "None", 200, 120, (0.2, 0.5)), "compiled v2, no acceleration")
+        # a small tree (20 spheres: the origin-relative instantiation, whose loops unroll over literal counts): compiled with or
+        # without the counts or refused -- whichever, the bytes are the oracle's
+        rng = np.random.default_rng(21)
+        sp = np.concatenate([rng.uniform(-1, 1, (20, 3)), rng.uniform(0.1, 0.3, (20, 1))], axis=1).astype(np.float32)
+        got = render(None, "BVH", 240, 160, (0.1, 0.3), spheres=sp)
+        assert "render_kernel_v2<" in ctx.last_kernel()
+        assert_same(got, cpu_render(oracle, None, "BVH", 240, 160, (0.1, 0.3), spheres=sp), "compiled v2, small tree")
+        assert ctx.rtc_status()[1] == 0 or "refused" in ctx.rtc_status()[2], ctx.rtc_status()
+        ctx.set_option("specialise_v2_after", 0)
+        got0 = render(3, "BVH", 320, 180, (0.3, 0.7))
+        assert tag not in ctx.last_kernel()
+        ctx.set_option("specialise_v2_after", 1)
+        assert_same(render(3, "BVH", 320, 180, (0.3, 0.7)), got0, "compiled v2 against the library's instantiation")
+    finally:
+        ctx.close()
+
+
 def test_background_compile_never_waits_and_takes_over(rm, gpu_ctx, oracle):
     """`specialise` = 2: the first renders of a new scene run in the ahead-of-time kernel while a background thread compiles; the
     scene's own kernel takes over when it is ready; every frame equals the oracle's."""

@@ -641,6 +641,20 @@ def main():
         apply_opts(False)
         ser = []
         with torch.cuda.stream(streams[0]):
+            # A configuration that keeps coming back gets the wave loop compiled for it (option specialise_v2_after, ~2 s on the
+            # host at that launch): untimed launches first, so that no timed one contains the compile.  The "first launch"
+            # figure (no item costs yet) is then taken with the longest-first order off -- the same thing.
+            for _ in range(max(0, ctx.get_option("specialise_v2_after"))):
+                tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0, shadedBuffer=b["rgba"], shader=wl["shader"])
+            torch.cuda.synchronize()
+            lpt_was = ctx.get_option("lpt")
+            ctx.set_option("lpt", 0)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            tracer.runRaymarcher(scene, b["depth"], b["normal"], b["sdf"], b["iters"], W, H, 0.0, shadedBuffer=b["rgba"], shader=wl["shader"])
+            c1.record()
+            torch.cuda.synchronize()
+            ctx.set_option("lpt", lpt_was)
             for _ in range(2 + 6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -651,7 +665,7 @@ def main():
                 torch.cuda.synchronize()
             kernel_alone = ctx.last_kernel()
             kern_ms = sum(a.elapsed_time(c) for a, c in ser[2:]) / len(ser[2:])
-            kern_ms_cold = ser[0][0].elapsed_time(ser[0][1])  # first launch after the option switch: no item costs recorded yet
+            kern_ms_cold = c0.elapsed_time(c1)  # no item costs: the queues' own order
             n_ser = max(5, min(20, args.steps))
             torch.cuda.synchronize()
             t0 = time.perf_counter()

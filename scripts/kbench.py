@@ -87,6 +87,9 @@ def main():
             bad = [k for k, t in (("depth", b["d"]), ("normal", b["n"]), ("sdf", b["s"]), ("iters", b["i"]), ("rgba", b["r"]))
                    if not (k == "rgba" and wl["shader"] == "phong") and hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() != g[k]]
             verdict = "golden OK" if not bad else "GOLDEN MISMATCH " + ",".join(bad)
+        for _ in range(max(0, ctx.get_option("specialise_v2_after"))):  # (the launch at which a configuration's own kernel is compiled is not timed)
+            render(b)
+        torch.cuda.synchronize()
         ev = []
         for _ in range(7):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

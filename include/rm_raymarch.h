@@ -386,6 +386,11 @@ RM_API int rm_debug_read_batch_log(rm_ctx *ctx, uint32_t *out196608);
  *                 compile at the first render; 2 = the same without waiting -- a background thread compiles, the ahead-of-time
  *                 kernels render meanwhile (same bytes), the scene's own kernel takes over when it is ready; 0 = the
  *                 ahead-of-time kernels only (the device interpreter of csrc/rm_program.h for operator trees)
+ *   specialise_v2_after 0..  the v2 wave loop: after this many launches with the same CONFIGURATION (frame size, shader, option
+ *                 switches, the scene's counts and grids, tile geometry, LDS layout -- csrc/rm_v2_fields.h; not the camera, not
+ *                 the rows of a launch) the kernel is compiled with that configuration's parameters as literals (~2 s; waiting
+ *                 for it or not as `specialise` says) and used from then on: C3 at 4K 1 190 -> 1 310 frames/s.  Default 3;
+ *                 0: never.  rm_last_kernel marks such launches "[launch constants compiled in]"
  *   rtc_spheres 0..33  sphere lists of fewer spheres than this (default 16) and primitive lists of up to 32 primitives are compiled
  *                 too, one single-leaf object per primitive, when their BVH has at most eight leaves (emitted as code: no node
  *                 walks in memory); they then run in the one-ray-per-lane kernel instead of the v2 wave loop

@@ -95,7 +95,12 @@ def main():
         path = os.path.join(PROF, "pmc_%s.json" % wl)
         pj = json.load(open(path))
         c = pj["counters_per_launch"]
-        mix, listing = static_mix(pj.get("kernel"))
+        kname = pj.get("kernel")
+        if kname and kname.startswith("rm_rtc_render_v2") and pj.get("kernel_reported"):
+            # the wave loop compiled for its configuration: the static mix of the unbucketed instructions is taken from the
+            # ahead-of-time instantiation it is a copy of (the literals remove scalar loads and dead branches, not the mix's shape)
+            kname = pj["kernel_reported"].split(" [")[0] + "(RmRenderParams)"
+        mix, listing = static_mix(kname)
         if mix is None:
             print("%s: kernel %r not found in the .s listings (run `make -C cpu_raymarcher_amd/csrc asm`)" % (wl, pj.get("kernel")))
             continue

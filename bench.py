@@ -371,8 +371,8 @@ def main():
             b = sets[k]
             if remaining is not None and args.tail_ramp and "blocks_per_cu" in in_flight_opts:
                 # the last frames of the burst find fewer and fewer other frames beside them: each brings more persistent
-                # workgroups of its own (4 = the library's default for a frame that runs alone)
-                ctx.set_option("blocks_per_cu", max(1, min(4, args.tail_ramp - remaining)) if remaining < args.tail_ramp else 1)
+                # workgroups of its own (up to six: what a CU holds)
+                ctx.set_option("blocks_per_cu", max(1, min(6, args.tail_ramp - remaining)) if remaining < args.tail_ramp else 1)
             if args.analytics_sweep:
                 scene.camera.rotateCamera(0, 0.015)  # main.ts:438-441
             with torch.cuda.stream(streams[k]):

@@ -693,7 +693,8 @@ int fill_params(rm_ctx *ctx, const rm_job *job, RmRenderParams &p) {
     // alone, 9 680 against 8 920 frames/s in flight.)
     if (p.variant == 0)
         p.variant = (ctx->host.accel == RM_ACCEL_OCTREE || ctx->host.spheres.size() < 8 ||
-                     (ctx->opt_specialise && !ctx->rtc_src.empty() && static_cast<int64_t>(ctx->host.spheres.size()) < ctx->opt_rtc_spheres))
+                     (ctx->opt_specialise && !ctx->rtc_src.empty() && rmrtc::available(nullptr) &&
+                      static_cast<int64_t>(ctx->host.spheres.size()) < ctx->opt_rtc_spheres))
                         ? 1
                         : 2;
     if (p.algorithm != RM_ALG_SPHERE_TRACER) p.variant = 1;  // the other marchers live in the v1 kernel
